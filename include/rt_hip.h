@@ -1,0 +1,179 @@
+/* rt_hip.h — C-ABI of the MI355X (gfx950) wavefront path-tracing core.
+ *
+ * Drop-in boundary for the reference renderer's CPU integrator: an
+ * `Integrator` subclass (src/cpu/Integrator.hpp:14-58) calls this library
+ * once per sample pass instead of running `Integrator::update()`
+ * (src/cpu/Integrator.cpp:26-67) on its 16-thread tile pool.  Plain pointers
+ * and sizes only; every call returns 0 on success or a negative rt_status,
+ * and rt_last_error() gives the text.  A context is used by one thread at a
+ * time (the reference drives its integrator from one render thread,
+ * src/cpu/Integrator.cpp:69-79).
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+enum rt_status {
+    RT_OK = 0,
+    RT_ERR_ARG = -1,      /* null / inconsistent argument */
+    RT_ERR_HIP = -2,      /* a HIP runtime call failed */
+    RT_ERR_NO_DEVICE = -3,/* no usable gfx950 device */
+    RT_ERR_LIMIT = -4,    /* size beyond what the context was created for */
+    RT_ERR_STATE = -5     /* call made in the wrong state (e.g. no camera) */
+};
+
+/* Light kinds of src/lights/LightSource.hpp:12-17 that the reference implements. */
+enum rt_light_type { RT_LIGHT_POINT = 0, RT_LIGHT_ENV = 3 };
+
+/* Per-model material: the part of MaterialUBO (src/scene/Material.hpp:17-21)
+ * that Material::computeBSDF reads (src/scene/Material.cpp:195-225). */
+typedef struct rt_material {
+    float diffuse_color[3];
+    float roughness;
+} rt_material;
+
+/* PointLight{pos = light2world*(0,0,0,1), I} (src/lights/PointLight.cpp:9-18)
+ * or EnvLight{RGBA32F lat-long image, scale} (src/lights/EnvLight.cpp:14-26). */
+typedef struct rt_light {
+    int32_t type;            /* rt_light_type */
+    float pos[3];            /* point only */
+    float intensity[3];      /* point: I; env: the `light` scale */
+    const float* env_rgba;   /* env only: env_w*env_h*4 floats, row-major */
+    int32_t env_w, env_h;
+} rt_light;
+
+/* The scene as BVH::runLBVH sees it (src/scene/BVH.cpp:293-317): all models'
+ * vertices concatenated, indices already offset by each model's vertex base,
+ * one model id per triangle.  Attribute pointers are strided because the
+ * byte layout of mango::sVertex is not part of the reference tree.  tangent
+ * and binormal may both be null: the library then derives an orthonormal
+ * frame from the shading normal. */
+typedef struct rt_scene_desc {
+    uint32_t n_vertices;
+    const float* pos;      uint32_t pos_stride;      /* strides in bytes */
+    const float* normal;   uint32_t normal_stride;
+    const float* uv;       uint32_t uv_stride;
+    const float* tangent;  uint32_t tangent_stride;
+    const float* binormal; uint32_t binormal_stride;
+    uint32_t n_indices;                               /* 3 * triangles */
+    const uint32_t* indices;
+    const int32_t* tri_model;                         /* n_indices/3 entries */
+    uint32_t n_models;
+    const rt_material* materials;                     /* one per model */
+    uint32_t n_lights;
+    const rt_light* lights;
+} rt_scene_desc;
+
+/* Compile-time constants of the reference made parameters: frame size
+ * (src/app/App.cpp:9-10), maxDepth=4 (src/cpu/PathTracer.cpp:15), tileSize=64
+ * (src/cpu/Integrator.hpp:56).  rank/world shard the film by interleaved
+ * tiles: tile t belongs to rank t % world. */
+typedef struct rt_params {
+    int32_t width, height;
+    int32_t max_depth;
+    int32_t tile_size;     /* 0 -> 64 */
+    uint64_t seed;
+    int32_t device;        /* HIP device ordinal */
+    int32_t rank, world;   /* world 0 or 1 -> whole film */
+    uint32_t max_rays;     /* capacity of rt_trace_* host-pointer calls; 0 -> width*height */
+} rt_params;
+
+typedef struct rt_stats {
+    uint64_t closest_rays;     /* closest-hit rays traced since create/reset */
+    uint64_t shadow_rays;      /* any-hit rays traced */
+    uint64_t passes;           /* sample passes accumulated (the reference's _frames) */
+    uint32_t n_nodes;          /* nodes of the reference-layout BVH (2T-1) */
+    uint32_t n_triangles;
+    int32_t bvh_max_depth;
+    uint32_t n_local_pixels;   /* pixels of this rank's tiles */
+    float last_trace_ms;       /* device time of the last rt_trace_* kernel (HIP events) */
+    float last_render_ms;      /* device time of the last rt_render call */
+    float bvh_build_ms;        /* host LBVH build, wall */
+} rt_stats;
+
+/* Replaces Integrator::Integrator (src/cpu/Integrator.cpp:7-15): builds the
+ * LBVH of src/scene/BVH.cpp:287-336 on the host, uploads scene and film. */
+int rt_create(const rt_scene_desc* scene, const rt_params* params, rt_ctx** out);
+void rt_destroy(rt_ctx* ctx);
+/* Error text of the last failed call on ctx (ctx may be null for rt_create). */
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* Replaces Integrator::nextFrame's camera snapshot (src/cpu/Integrator.cpp:85-92).
+ * A changed camera restarts accumulation like src/cpu/Integrator.cpp:27-30. */
+int rt_set_camera(rt_ctx* ctx, const float pos[3], const float right[3], const float up[3],
+                  const float forward[3]);
+int rt_reset_accumulation(rt_ctx* ctx);
+
+/* Replaces n_passes calls of Integrator::update (src/cpu/Integrator.cpp:26-67),
+ * each one PathTracer::computeTile over every tile of this rank
+ * (src/cpu/PathTracer.cpp:17-164): one sample per pixel per pass, running mean. */
+int rt_render(rt_ctx* ctx, uint32_t n_passes);
+
+/* Replaces Integrator::sync (src/cpu/Integrator.cpp:21-24): the linear
+ * RGBA32F film, row-major, y=0 at the top, width*height*4 floats.  Pixels of
+ * other ranks' tiles are written as zero. */
+int rt_read_film(rt_ctx* ctx, float* rgba_out);
+
+/* This rank's packed tile slab on the device: n_tiles*tile*tile*4 floats,
+ * tiles in increasing global tile index.  For gathering the film across ranks. */
+int rt_film_slab(rt_ctx* ctx, const float** device_ptr, uint32_t* n_tiles, uint64_t* n_floats);
+/* Copies the slab into caller-owned device memory (n_floats from rt_film_slab). */
+int rt_copy_film_slab(rt_ctx* ctx, void* device_dst, uint64_t n_floats);
+/* Scatters a gathered set of slabs (rank-major, each padded to
+ * slab_floats_per_rank) into a width*height*4 host film. */
+int rt_unpack_slabs(int32_t width, int32_t height, int32_t tile_size, int32_t world,
+                    const float* slabs_host, uint64_t slab_floats_per_rank, float* rgba_out);
+
+/* BVH::intersect (src/scene/BVH.cpp:49-61,129-170) over n rays.  rays: six
+ * planes ox,oy,oz,dx,dy,dz of n floats (host memory).  Outputs (host, n
+ * entries each): dist (+inf on a miss), id0 = model index, id1 = index-buffer
+ * offset of the triangle (both -1 on a miss), barycentrics u,v. */
+int rt_trace_closest(rt_ctx* ctx, uint32_t n, const float* rays_soa, float* dist, int32_t* id0,
+                     int32_t* id1, float* u, float* v);
+/* BVH::occluded (src/scene/BVH.cpp:63-127): status[i] = 1 if anything is hit. */
+int rt_trace_occluded(rt_ctx* ctx, uint32_t n, const float* rays_soa, int32_t* status);
+
+/* The same two with every buffer already in device memory (HBM-resident
+ * inputs; the benchmark path).  Launches on the context's stream; `repeat`
+ * back-to-back launches are timed together with HIP events on that stream
+ * and the mean per-launch time is stored in rt_stats.last_trace_ms. */
+int rt_trace_closest_dev(rt_ctx* ctx, uint32_t n, const float* d_rays_soa, float* d_dist,
+                         int32_t* d_id0, int32_t* d_id1, float* d_u, float* d_v, uint32_t repeat);
+int rt_trace_occluded_dev(rt_ctx* ctx, uint32_t n, const float* d_rays_soa, int32_t* d_status,
+                          uint32_t repeat);
+
+/* The LBVH in the reference's node layout (src/scene/BBox.hpp:27-56), for
+ * checking tree identity: boxes n*6 floats (min xyz, max xyz); left, right,
+ * tri (triIds[0]), model (modelIds[0]), leaf: n int32 each.  Pass nulls to
+ * query n_nodes only. */
+int rt_get_bvh(rt_ctx* ctx, uint32_t* n_nodes, float* boxes, int32_t* left, int32_t* right,
+               int32_t* tri, int32_t* model, int32_t* leaf);
+
+/* Host-only run of the same LBVH builder (no device needed): fills the
+ * reference-layout node arrays for n_indices/3 triangles; every array holds
+ * 2*(n_indices/3)-1 entries.  Replaces BVH::runLBVH (src/scene/BVH.cpp:287-336)
+ * for callers that only want the tree. */
+int rt_lbvh_host(const float* pos, uint32_t pos_stride, const uint32_t* indices, uint32_t n_indices,
+                 const int32_t* tri_model, int32_t* max_depth, float* boxes, int32_t* left, int32_t* right,
+                 int32_t* tri, int32_t* model, int32_t* leaf);
+/* Morton code of src/scene/BVH.cpp:189-212 for a point of the unit cube. */
+uint32_t rt_morton3d(float x, float y, float z);
+
+int rt_get_stats(rt_ctx* ctx, rt_stats* out);
+int rt_synchronize(rt_ctx* ctx);
+
+/* Library identity: "rt_hip <version> gfx950". */
+const char* rt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_HIP_H */

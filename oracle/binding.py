@@ -1,0 +1,183 @@
+"""ctypes binding of oracle/liboracle.so.  TEST INFRASTRUCTURE ONLY: imported
+by tests/, the smoke check and bench.py's cpu_baseline leg; never by the
+raytracer_amd package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_DIR, "liboracle.so")
+_lib = None
+
+
+class orc_light_desc(C.Structure):
+    _fields_ = [("type", C.c_int32), ("pos", C.c_float * 3), ("intensity", C.c_float * 3),
+                ("env_rgba", C.POINTER(C.c_float)), ("env_w", C.c_int32), ("env_h", C.c_int32)]
+
+
+def build():
+    subprocess.check_call(["make", "-C", _DIR, "-s"])
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_PATH):
+        build()
+    L = C.CDLL(_PATH)
+    vp, fp, ip, up = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+    u64p = C.POINTER(C.c_uint64)
+    L.orc_create.restype = vp
+    L.orc_create.argtypes = [C.c_uint32, fp, fp, fp, fp, fp, C.c_uint32, up, ip, C.c_uint32, fp, C.c_uint32,
+                             C.POINTER(orc_light_desc)]
+    L.orc_destroy.argtypes = [vp]
+    L.orc_bvh_info.argtypes = [vp, up, ip]
+    L.orc_bvh_nodes.argtypes = [vp, fp, ip, ip, ip, ip, ip]
+    L.orc_intersect.argtypes = [vp, C.c_uint64, fp, fp, ip, ip, fp, fp, u64p, C.c_int]
+    L.orc_occluded.argtypes = [vp, C.c_uint64, fp, ip, u64p]
+    L.orc_brute_force.argtypes = [vp, C.c_uint64, fp, fp, ip]
+    L.orc_render.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, fp, u64p]
+    L.orc_camera_rays.argtypes = [fp, C.c_int, C.c_int, fp]
+    L.orc_morton3d.restype = C.c_uint32
+    L.orc_morton3d.argtypes = [C.c_float] * 3
+    L.orc_expand_bits.restype = C.c_uint32
+    L.orc_expand_bits.argtypes = [C.c_uint32]
+    L.orc_intersect_bbox.argtypes = [fp, fp, fp, fp, fp]
+    L.orc_intersect_triangle.argtypes = [fp, fp, fp, fp, fp, fp]
+    L.orc_cosine_sample_hemisphere.argtypes = [C.c_float, C.c_float, fp]
+    L.orc_diffuse_f.argtypes = [fp, C.c_float, fp, fp, fp]
+    L.orc_diffuse_sample.restype = C.c_float
+    L.orc_diffuse_sample.argtypes = [fp, C.c_float, fp, C.c_float, C.c_float, fp, fp]
+    L.orc_power_heuristic.restype = C.c_float
+    L.orc_power_heuristic.argtypes = [C.c_float, C.c_float]
+    L.orc_dist1d_sample.restype = C.c_float
+    L.orc_dist1d_sample.argtypes = [fp, C.c_int, C.c_float, fp, ip]
+    L.orc_dist1d_cdf.argtypes = [fp, C.c_int, fp, fp]
+    L.orc_dist2d_sample.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp]
+    L.orc_dist2d_pdf.restype = C.c_float
+    L.orc_dist2d_pdf.argtypes = [fp, C.c_int, C.c_int, C.c_float, C.c_float]
+    L.orc_rng_u01.restype = C.c_float
+    L.orc_rng_u01.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+    L.orc_light_sample.argtypes = [vp, C.c_int, fp, C.c_float, C.c_float, fp, fp, fp]
+    L.orc_light_pdf.restype = C.c_float
+    L.orc_light_pdf.argtypes = [vp, C.c_int, fp]
+    L.orc_light_le.argtypes = [vp, C.c_int, fp, fp]
+    _lib = L
+    return L
+
+
+def _f(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def f3(*v):
+    return np.asarray(v, np.float32)
+
+
+class OracleScene:
+    """The CPU restatement of the reference path over one scene."""
+
+    def __init__(self, scene, use_frame: bool = True):
+        L = lib()
+        self._L = L
+        s = scene
+        self._keep = []
+        lights = (orc_light_desc * max(1, len(s.lights)))()
+        for k, l in enumerate(s.lights):
+            lights[k].type = l.type
+            lights[k].pos[:] = [float(x) for x in l.pos]
+            lights[k].intensity[:] = [float(x) for x in l.intensity]
+            if l.env is not None:
+                env = np.ascontiguousarray(l.env, np.float32)
+                self._keep.append(env)
+                lights[k].env_rgba = _f(env)
+                lights[k].env_h, lights[k].env_w = env.shape[0], env.shape[1]
+        mats = np.ascontiguousarray(s.materials, np.float32)
+        self._h = L.orc_create(s.pos.shape[0], _f(s.pos), _f(s.normal), _f(s.uv),
+                               _f(s.tangent) if use_frame else None, _f(s.binormal) if use_frame else None,
+                               s.indices.size, s.indices.ctypes.data_as(C.POINTER(C.c_uint32)), _i(s.tri_model),
+                               s.n_models, _f(mats), len(s.lights), lights)
+        self.scene = s
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._L.orc_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def bvh_info(self):
+        n, d = C.c_uint32(), C.c_int32()
+        self._L.orc_bvh_info(self._h, C.byref(n), C.byref(d))
+        return n.value, d.value
+
+    def bvh_nodes(self):
+        n, _ = self.bvh_info()
+        boxes = np.empty((n, 6), np.float32)
+        arrs = [np.empty(n, np.int32) for _ in range(5)]
+        self._L.orc_bvh_nodes(self._h, _f(boxes), *[_i(a) for a in arrs])
+        return (boxes, *arrs)
+
+    def intersect(self, rays, counters=False, threads=1):
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[1]
+        t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
+        id0 = np.empty(n, np.int32); id1 = np.empty(n, np.int32)
+        cnt = (C.c_uint64 * 3)()
+        self._L.orc_intersect(self._h, n, _f(rays), _f(t), _i(id0), _i(id1), _f(u), _f(v), cnt if counters else None, threads)
+        if counters:
+            return t, id0, id1, u, v, {"n_inner": cnt[0], "n_tri": cnt[1], "n_rays": cnt[2]}
+        return t, id0, id1, u, v
+
+    def occluded(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[1]
+        st = np.empty(n, np.int32)
+        self._L.orc_occluded(self._h, n, _f(rays), _i(st), None)
+        return st
+
+    def brute_force(self, rays):
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[1]
+        t = np.empty(n, np.float32); id1 = np.empty(n, np.int32)
+        self._L.orc_brute_force(self._h, n, _f(rays), _f(t), _i(id1))
+        return t, id1
+
+    def render(self, cam, W, H, max_depth, seed, n_passes, threads=8, film=None, first_pass=0):
+        if film is None:
+            film = np.zeros((H, W, 4), np.float32)
+        cnt = (C.c_uint64 * 2)()
+        c = cam.packed()
+        self._L.orc_render(self._h, _f(c), W, H, max_depth, seed, first_pass, n_passes, threads, _f(film), cnt)
+        return film, {"closest": cnt[0], "shadow": cnt[1]}
+
+    def light_sample(self, l, p, u0, u1):
+        in3, li3 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        pdf = C.c_float()
+        self._L.orc_light_sample(self._h, l, _f(f3(*p)), u0, u1, _f(in3), C.byref(pdf), _f(li3))
+        return in3, pdf.value, li3
+
+    def light_pdf(self, l, d):
+        return self._L.orc_light_pdf(self._h, l, _f(f3(*d)))
+
+    def light_le(self, l, d):
+        le = np.zeros(3, np.float32)
+        self._L.orc_light_le(self._h, l, _f(f3(*d)), _f(le))
+        return le
+
+
+def camera_rays(cam, W, H):
+    rays = np.empty((6, W * H), np.float32)
+    c = cam.packed()
+    lib().orc_camera_rays(_f(c), W, H, _f(rays))
+    return rays

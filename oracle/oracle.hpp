@@ -1,0 +1,855 @@
+// CPU oracle: TEST INFRASTRUCTURE ONLY.
+//
+// A scalar restatement of the reference renderer's CPU path-tracing path
+// (kurono267/Raytracer), used as the checker for the HIP library and as the
+// timed CPU baseline.  Nothing in the shipped product may include, link or
+// call this file; only tests/, the smoke check and the cpu_baseline leg of
+// bench.py do.
+//
+// PARITY UNPINNED: the reference holds no tests, golden vectors or fixtures
+// for this path, and it cannot be compiled here (its Mango / simd / glm
+// dependencies are absent).  Fidelity rests on line-by-line correspondence
+// with the cited reference lines and on known-answer tests of the
+// reference's observable quirks.
+//
+// Floating-point model: IEEE-754 binary32, round-to-nearest, no FMA
+// contraction (compile with -ffp-contract=off), correctly rounded / and
+// sqrt, every expression evaluated in the operand order written here, which
+// is the order glm's generic (non-SIMD) definitions give the cited reference
+// expressions.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <thread>
+#include <vector>
+
+namespace orc {
+
+// ---------------------------------------------------------------- vec math
+// glm generic definitions: dot3 = a.x*b.x + a.y*b.y + a.z*b.z (left to
+// right), cross, normalize = v * (1/sqrt(dot(v,v))), min(x,y)=(y<x)?y:x,
+// max(x,y)=(x<y)?y:x.
+struct vec2 { float x, y; };
+struct vec3 {
+    float x, y, z;
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+};
+inline vec3 V3(float a) { return {a, a, a}; }
+inline vec3 operator+(vec3 a, vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline vec3 operator-(vec3 a, vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline vec3 operator-(vec3 a) { return {-a.x, -a.y, -a.z}; }
+inline vec3 operator*(vec3 a, vec3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline vec3 operator*(vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline vec3 operator*(float s, vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline vec3 operator/(vec3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline vec3 operator/(vec3 a, vec3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline vec3 operator/(float s, vec3 a) { return {s / a.x, s / a.y, s / a.z}; }
+inline float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline vec3 cross(vec3 x, vec3 y) {
+    return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y};
+}
+inline float gmin(float x, float y) { return (y < x) ? y : x; }
+inline float gmax(float x, float y) { return (x < y) ? y : x; }
+inline vec3 gmin(vec3 a, vec3 b) { return {gmin(a.x, b.x), gmin(a.y, b.y), gmin(a.z, b.z)}; }
+inline vec3 gmax(vec3 a, vec3 b) { return {gmax(a.x, b.x), gmax(a.y, b.y), gmax(a.z, b.z)}; }
+inline vec3 normalize(vec3 v) { return v * (1.0f / std::sqrt(dot(v, v))); }
+inline float length2(vec3 v) { return dot(v, v); }
+inline bool is_zero(vec3 v) { return v.x == 0.0f && v.y == 0.0f && v.z == 0.0f; }
+
+// src/scene/Common.hpp:9-11 (std::max(std::min(v,hi),lo))
+inline float clampf(float v, float lo, float hi) { return std::max(std::min(v, hi), lo); }
+
+// src/scene/Common.hpp:27-30
+inline float powerHeuristic(int nf, float fPdf, int ng, float gPdf) {
+    float f = nf * fPdf, g = ng * gPdf;
+    return (f * f) / (f * f + g * g);
+}
+
+// src/scene/Common.hpp:13-25; the final clamp runs in float and converts back
+template <typename Pred>
+inline int findInterval(int size, const Pred& pred) {
+    int first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (pred(middle)) {
+            first = middle + 1;
+            len -= half + 1;
+        } else
+            len = half;
+    }
+    return (int)clampf((float)(first - 1), (float)0, (float)(size - 2));
+}
+
+// ------------------------------------------------- deterministic sampler
+// Replaces std::mt19937(std::random_device()) of src/cpu/PathTracer.cpp:20-22,
+// which cannot be reproduced run to run.  Counter based: one draw is a pure
+// function of (seed, pixel, pass, dimension).
+inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline float rng_u01(uint64_t seed, uint32_t pixel, uint32_t pass, uint32_t dim) {
+    uint64_t ctr = ((uint64_t)pass << 48) ^ ((uint64_t)pixel << 16) ^ (uint64_t)dim;
+    uint64_t z = splitmix64(splitmix64(seed) ^ ctr);
+    return (float)(z >> 40) * 0x1p-24f;
+}
+
+// ------------------------------------------------------------ Ray / hit
+// src/scene/Ray.hpp:10-24
+struct Ray {
+    vec3 org, dir, invdir;
+    Ray() = default;
+    Ray(vec3 o, vec3 d) : org(o), dir(d) {
+        invdir = 1.0f / dir;
+        if (dir.x == 0.0f) invdir.x = 0.0f;
+        if (dir.y == 0.0f) invdir.y = 0.0f;
+        if (dir.z == 0.0f) invdir.z = 0.0f;
+    }
+};
+// src/scene/Ray.hpp:26-35, Ray.cpp:9-15
+struct RayHit {
+    bool status = false;
+    float dist = std::numeric_limits<float>::infinity();
+    int id0 = -1, id1 = -1;
+    vec3 bc = {0.f, 0.f, 0.f};
+};
+struct BBox {
+    vec3 min = V3(std::numeric_limits<float>::infinity());
+    vec3 max = V3(-std::numeric_limits<float>::infinity());
+    // src/scene/BBox.cpp:10-17
+    void expand(vec3 mn, vec3 mx) { min = gmin(mn, min); max = gmax(mx, max); }
+};
+
+// src/scene/Ray.cpp:17-34
+inline RayHit intersectBBox(const Ray& ray, const BBox& box) {
+    RayHit hit;
+    vec3 lov = ray.invdir * (box.min - ray.org);
+    vec3 hiv = ray.invdir * (box.max - ray.org);
+    vec3 max_v = gmax(lov, hiv);
+    vec3 min_v = gmin(lov, hiv);
+    float tmin = gmax(min_v.x, gmax(min_v.y, min_v.z));
+    float tmax = gmin(max_v.x, gmin(max_v.y, max_v.z));
+    if (tmin <= tmax && (tmax > 0.0f)) {
+        hit.dist = tmin;
+        hit.status = true;
+    }
+    return hit;
+}
+
+// src/scene/Ray.cpp:36-67
+inline RayHit intersectTriangle(const Ray& ray, vec3 v0, vec3 v1, vec3 v2) {
+    RayHit hit;
+    vec3 e1 = v1 - v0;
+    vec3 e2 = v2 - v0;
+    vec3 pvec = cross(ray.dir, e2);
+    float det = dot(e1, pvec);
+    if ((double)std::fabs(det) < 1e-8) return hit;  // double-typed literal
+    float inv_det = 1 / det;
+    vec3 tvec = ray.org - v0;
+    float u = dot(tvec, pvec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return hit;
+    vec3 qvec = cross(tvec, e1);
+    float v = dot(ray.dir, qvec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return hit;
+    hit.dist = dot(e2, qvec) * inv_det;
+    hit.status = true;
+    hit.bc = {1.0f - u - v, u, v};
+    return hit;
+}
+
+// ------------------------------------------------------------------ BVH
+// src/scene/BBox.hpp:27-56 (the fields the scalar path reads)
+struct BVHNode {
+    BBox box;
+    int left = -1, right = -1;
+    int tri = -1;      // triIds[0]: index-buffer offset of the triangle
+    int model = -1;    // modelIds[0]
+    int depth = 0;
+    bool isLeaf = false;
+};
+
+struct Vertex {
+    vec3 pos{0, 0, 0}, normal{0, 0, 0};
+    vec2 uv{0, 0};
+    vec3 tangent{0, 0, 0}, binormal{0, 0, 0};
+};
+
+// src/scene/BVH.cpp:191-198
+inline uint32_t expandBits(uint32_t v) {
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+// src/scene/BVH.cpp:202-212; glm::clamp = min(max(x,lo),hi)
+inline uint32_t morton3D(vec3 v) {
+    auto c = [](float a) { return gmin(gmax(a * 1024.f, 0.f), 1023.f); };
+    float x = c(v.x), y = c(v.y), z = c(v.z);
+    // a NaN coordinate (flat scene axis: 0/0) is an undefined conversion in
+    // the reference; both sides here define it as cell 0
+    uint32_t xx = expandBits(x == x ? (uint32_t)x : 0u);
+    uint32_t yy = expandBits(y == y ? (uint32_t)y : 0u);
+    uint32_t zz = expandBits(z == z ? (uint32_t)z : 0u);
+    return xx * 4 + yy * 2 + zz;
+}
+
+struct Counters {
+    uint64_t n_inner = 0;  // inner nodes visited (2 child box tests each)
+    uint64_t n_tri = 0;    // triangle tests
+    uint64_t n_rays = 0;
+};
+
+struct BVH {
+    struct Prim {
+        vec3 minBox = V3(std::numeric_limits<float>::infinity());
+        vec3 maxBox = V3(-std::numeric_limits<float>::infinity());
+        vec3 center{0, 0, 0};
+        int id = 0, modelId = 0;
+        uint32_t mortonCode = 0;
+    };
+    std::vector<uint32_t> indices;
+    std::vector<Vertex> vertices;
+    std::vector<BVHNode> nodes;
+    size_t rootId = 0;
+    int maxDepth = 0;
+
+    // src/scene/BVH.cpp:214-240 (std::__clz -> __builtin_clz)
+    static uint32_t findSplit(const std::vector<Prim>& p, uint32_t start, uint32_t end) {
+        uint32_t startMorton = p[start].mortonCode, endMorton = p[end].mortonCode;
+        if (startMorton == endMorton) return (start + end) >> 1;
+        int commonPrefix = __builtin_clz(startMorton ^ endMorton);
+        uint32_t split = start, step = end - start;
+        do {
+            step = (step + 1) >> 1;
+            uint32_t newSplit = split + step;
+            if (newSplit < end) {
+                uint32_t splitCode = p[newSplit].mortonCode;
+                // identical codes: clz(0) is undefined; treat as the longest prefix
+                uint32_t x = startMorton ^ splitCode;
+                int splitPrefix = x ? __builtin_clz(x) : 32;
+                if (splitPrefix > commonPrefix) split = newSplit;
+            }
+        } while (step > 1);
+        return split;
+    }
+
+    // src/scene/BVH.cpp:242-285
+    void recursive(BVHNode& root, const std::vector<Prim>& p, uint32_t start, uint32_t end, int depth) {
+        if (maxDepth < depth) maxDepth = depth;
+        BBox aabb;
+        for (uint32_t i = start; i <= end; ++i) aabb.expand(p[i].minBox, p[i].maxBox);
+        root.box = aabb;
+        uint32_t size = end - start + 1;
+        if (size <= 1) {
+            root.isLeaf = true;
+            root.tri = p[start].id;
+            root.model = p[start].modelId;
+            return;
+        }
+        uint32_t split = findSplit(p, start, end);
+        BVHNode left, right;
+        nodes.push_back(left);
+        root.left = (int)nodes.size() - 1;
+        nodes.push_back(right);
+        root.right = (int)nodes.size() - 1;
+        recursive(left, p, start, split, depth + 1);
+        recursive(right, p, split + 1, end, depth + 1);
+        nodes[root.left] = left;
+        nodes[root.right] = right;
+        root.depth = depth;
+    }
+
+    // src/scene/BVH.cpp:287-336.  `verts`/`idx` are the already flattened
+    // arrays (indices offset by vbOffset), `triModel` the model of each
+    // triangle; Prim.id is the offset of the triangle's first index.
+    void runLBVH(const std::vector<Vertex>& verts, const std::vector<uint32_t>& idx,
+                 const std::vector<int>& triModel) {
+        vertices = verts;
+        indices = idx;
+        std::vector<Prim> prims;
+        BBox mainBox;
+        for (size_t i = 0; i + 2 < idx.size(); i += 3) {
+            Prim prim;
+            for (int v = 0; v < 3; ++v) {
+                vec3 vPos = verts[idx[i + v]].pos;
+                prim.minBox = gmin(prim.minBox, vPos);
+                prim.maxBox = gmax(prim.maxBox, vPos);
+                prim.center = prim.center + vPos;
+            }
+            prim.id = (int)i;
+            prim.modelId = triModel[i / 3];
+            mainBox.min = gmin(prim.minBox, mainBox.min);
+            mainBox.max = gmax(prim.maxBox, mainBox.max);
+            prim.center = prim.center / 3.0f;
+            prims.push_back(prim);
+        }
+        for (auto& p : prims) {
+            vec3 n = (p.center - mainBox.min) / (mainBox.max - mainBox.min);
+            p.mortonCode = morton3D(n);
+        }
+        // reference: std::sort (unstable); ties broken by Prim.id here, which
+        // is one of the orders std::sort may legally produce
+        std::stable_sort(prims.begin(), prims.end(),
+                         [](const Prim& a, const Prim& b) { return a.mortonCode < b.mortonCode; });
+        nodes.clear();
+        nodes.emplace_back();
+        rootId = 0;
+        maxDepth = 0;
+        if (prims.empty()) return;
+        BVHNode root;
+        recursive(root, prims, 0, (uint32_t)prims.size() - 1, 0);
+        nodes[rootId] = root;
+    }
+
+    // src/scene/BVH.cpp:129-170
+    void intersectRec(const Ray& ray, RayHit& hit, const BVHNode& curr, Counters* c) const {
+        if (curr.isLeaf) {
+            int triId = curr.tri;
+            if (triId >= 0) {
+                if (c) c->n_tri++;
+                uint32_t i0 = indices[triId], i1 = indices[triId + 1], i2 = indices[triId + 2];
+                RayHit test = intersectTriangle(ray, vertices[i0].pos, vertices[i1].pos, vertices[i2].pos);
+                if (test.status && test.dist > 0.0001f && test.dist < hit.dist) {
+                    hit = test;
+                    hit.id1 = triId;
+                    hit.id0 = curr.model;
+                }
+            }
+        } else {
+            if (c) c->n_inner++;
+            const BVHNode& leftNode = nodes[curr.left];
+            const BVHNode& rightNode = nodes[curr.right];
+            RayHit left = intersectBBox(ray, leftNode.box);
+            RayHit right = intersectBBox(ray, rightNode.box);
+            bool leftStatus = left.status && left.dist < hit.dist;
+            bool rightStatus = right.status && right.dist < hit.dist;
+            if (leftStatus && rightStatus) {
+                if (right.dist < left.dist) {
+                    intersectRec(ray, hit, rightNode, c);
+                    intersectRec(ray, hit, leftNode, c);
+                } else {
+                    intersectRec(ray, hit, leftNode, c);
+                    intersectRec(ray, hit, rightNode, c);
+                }
+            } else if (leftStatus)
+                intersectRec(ray, hit, leftNode, c);
+            else if (rightStatus)
+                intersectRec(ray, hit, rightNode, c);
+        }
+    }
+    // src/scene/BVH.cpp:49-61
+    RayHit intersect(const Ray& ray, Counters* c = nullptr) const {
+        if (c) c->n_rays++;
+        RayHit hit = intersectBBox(ray, nodes[rootId].box);
+        if (!hit.status) return hit;
+        hit.status = false;
+        hit.dist = std::numeric_limits<float>::infinity();
+        intersectRec(ray, hit, nodes[rootId], c);
+        return hit;
+    }
+    // src/scene/BVH.cpp:35-45,63-127
+    RayHit occluded(const Ray& ray, Counters* c = nullptr) const {
+        if (c) c->n_rays++;
+        RayHit hit = intersectBBox(ray, nodes[rootId].box);
+        if (!hit.status) return hit;
+        hit.status = false;
+        hit.dist = std::numeric_limits<float>::infinity();
+        const int MAX_STACK = 128;
+        int stack[MAX_STACK];
+        int top = 0;
+        stack[0] = (int)rootId;
+        auto add = [&](int id) { if (top < MAX_STACK - 1) stack[++top] = id; };
+        while (top >= 0) {
+            int currId = stack[top--];
+            const BVHNode& curr = nodes[currId];
+            if (curr.isLeaf) {
+                int triId = curr.tri;
+                if (triId >= 0) {
+                    if (c) c->n_tri++;
+                    uint32_t i0 = indices[triId], i1 = indices[triId + 1], i2 = indices[triId + 2];
+                    RayHit test = intersectTriangle(ray, vertices[i0].pos, vertices[i1].pos, vertices[i2].pos);
+                    if (test.status && test.dist > 0.0001f) {
+                        hit = test;
+                        hit.id1 = triId;
+                        hit.id0 = curr.model;
+                        return hit;
+                    }
+                }
+            } else {
+                if (c) c->n_inner++;
+                int leftID = curr.left, rightID = curr.right;
+                RayHit left = intersectBBox(ray, nodes[leftID].box);
+                RayHit right = intersectBBox(ray, nodes[rightID].box);
+                bool leftStatus = left.status && left.dist < hit.dist;
+                bool rightStatus = right.status && right.dist < hit.dist;
+                if (leftStatus && rightStatus) {
+                    if (right.dist < left.dist) std::swap(leftID, rightID);
+                    add(rightID);
+                    add(leftID);
+                } else if (leftStatus)
+                    add(leftID);
+                else if (rightStatus)
+                    add(rightID);
+            }
+        }
+        return hit;
+    }
+    // src/scene/BVH.cpp:172-187.  The accumulation starts from a zeroed vertex.
+    Vertex postIntersect(const Ray& ray, const RayHit& hit, bool haveFrame) const {
+        Vertex h;
+        h.pos = ray.org + ray.dir * hit.dist;
+        for (int v = 0; v < 3; ++v) {
+            const Vertex& vert = vertices[indices[hit.id1 + v]];
+            float b = hit.bc[v];
+            h.normal = h.normal + vert.normal * b;
+            h.uv = {h.uv.x + vert.uv.x * b, h.uv.y + vert.uv.y * b};
+            h.tangent = h.tangent + vert.tangent * b;
+            h.binormal = h.binormal + vert.binormal * b;
+        }
+        h.normal = normalize(h.normal);
+        if (haveFrame) {
+            h.binormal = normalize(h.binormal);
+            h.tangent = normalize(h.tangent);
+        } else {
+            // Divergence from the reference (it would normalise a zero vector
+            // into NaN for meshes without tangents): a deterministic
+            // orthonormal frame built from the normal.
+            vec3 n = h.normal, t;
+            if (std::fabs(n.x) > std::fabs(n.y)) {
+                float il = 1.0f / std::sqrt(n.x * n.x + n.z * n.z);
+                t = {-n.z * il, 0.0f, n.x * il};
+            } else {
+                float il = 1.0f / std::sqrt(n.y * n.y + n.z * n.z);
+                t = {0.0f, n.z * il, -n.y * il};
+            }
+            h.tangent = t;
+            h.binormal = cross(n, t);
+        }
+        return h;
+    }
+};
+
+// ----------------------------------------------------------------- BSDF
+constexpr float INV_PI = 1.0f / (float)M_PI;             // src/bsdf/Samples.hpp:10-13
+constexpr float INV_2PI = 1.0f / (2.f * (float)M_PI);
+constexpr float PI_OVER_2 = (float)M_PI / 2.f;
+constexpr float PI_OVER_4 = PI_OVER_2 / 2.f;
+
+// src/bsdf/Samples.hpp:15-28
+inline vec2 concentricSampleDisk(vec2 u) {
+    vec2 uo = {2.f * u.x - 1.f, 2.f * u.y - 1.f};
+    if (uo.x == 0 && uo.y == 0) return {0.f, 0.f};
+    float theta, r;
+    if (std::fabs(uo.x) > std::fabs(uo.y)) {
+        r = uo.x;
+        theta = PI_OVER_4 * (uo.y / uo.x);
+    } else {
+        r = uo.y;
+        theta = PI_OVER_2 - PI_OVER_4 * (uo.x / uo.y);
+    }
+    return {r * std::cos(theta), r * std::sin(theta)};
+}
+// src/bsdf/Samples.hpp:30-34 — the cosine-weighted "up" goes into y
+inline vec3 cosineSampleHemisphere(vec2 u) {
+    vec2 d = concentricSampleDisk(u);
+    float z = std::sqrt(std::max(0.f, 1.f - d.x * d.x - d.y * d.y));
+    return {d.x, z, d.y};
+}
+// src/bsdf/Samples.hpp:36-43
+inline float sphericalTheta(vec3 v) { return std::acos(clampf(v.y, -1.f, 1.f)); }
+inline float sphericalPhi(vec3 v) {
+    float p = std::atan2(-v.z, -v.x);
+    return (p < 0.f) ? (p + 2.f * (float)M_PI) : p;
+}
+
+// src/bsdf/BxDF.hpp:38-64
+inline float cosTheta(vec3 w) { return w.z; }
+inline float absCosTheta(vec3 w) { return std::fabs(w.z); }
+inline float sin2Theta(vec3 w) { return std::max(0.f, 1.f - w.z * w.z); }
+inline float sinTheta(vec3 w) { return std::sqrt(sin2Theta(w)); }
+inline float cosPhi(vec3 w) { float s = sinTheta(w); return (s == 0) ? 1 : clampf(w.x / s, -1, 1); }
+inline float sinPhi(vec3 w) { float s = sinTheta(w); return (s == 0) ? 0 : clampf(w.y / s, -1, 1); }
+inline bool sameHemisphere(vec3 w, vec3 wp) { return w.z * wp.z > 0; }
+
+// src/bsdf/Diffuse.cpp:7-32 (Oren-Nayar; sigma used as given)
+struct Diffuse {
+    vec3 color;
+    float A, B;
+    Diffuse() = default;
+    Diffuse(vec3 c, float sigma) : color(c) {
+        float sigma2 = sigma * sigma;
+        A = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+        B = 0.45f * sigma2 / (sigma2 + 0.09f);
+    }
+    vec3 f(vec3 out, vec3 in) const {
+        float sinThetaI = sinTheta(in), sinThetaO = sinTheta(out);
+        float maxCos = 0;
+        if ((double)sinThetaI > 1e-4 && (double)sinThetaO > 1e-4) {
+            float sinPhiI = sinPhi(in), cosPhiI = cosPhi(in);
+            float sinPhiO = sinPhi(out), cosPhiO = cosPhi(out);
+            float dCos = cosPhiI * cosPhiO + sinPhiI * sinPhiO;
+            maxCos = std::max(0.f, dCos);
+        }
+        float sinAlpha, tanBeta;
+        if (absCosTheta(in) > absCosTheta(out)) {
+            sinAlpha = sinThetaO;
+            tanBeta = sinThetaI / absCosTheta(in);
+        } else {
+            sinAlpha = sinThetaI;
+            tanBeta = sinThetaO / absCosTheta(out);
+        }
+        return color * INV_PI * (A + B * maxCos * sinAlpha * tanBeta);
+    }
+    // src/bsdf/BxDF.cpp:15-17
+    float pdf(vec3 out, vec3 in) const { return sameHemisphere(out, in) ? absCosTheta(in) * INV_PI : 0; }
+    // src/bsdf/BxDF.cpp:8-13
+    vec3 sampled(vec3 out, vec2 u, vec3& in, float& p) const {
+        in = cosineSampleHemisphere(u);
+        if (out.z < 0) in.z *= -1;
+        p = pdf(out, in);
+        return f(out, in);
+    }
+};
+
+// src/bsdf/BSDF.cpp:7-104 with exactly one lobe (the only configuration
+// src/scene/Material.cpp:195-225 ever builds)
+struct BSDF {
+    vec3 t, b, n;
+    Diffuse lobe;
+    BSDF() = default;
+    BSDF(const Vertex& v, const Diffuse& d) : t(v.tangent), b(v.binormal), n(v.normal), lobe(d) {}
+    vec3 world2local(vec3 v) const { return {dot(t, v), dot(b, v), dot(n, v)}; }
+    vec3 local2world(vec3 v) const {
+        return {t.x * v.x + b.x * v.y + n.x * v.z, t.y * v.x + b.y * v.y + n.y * v.z,
+                t.z * v.x + b.z * v.y + n.z * v.z};
+    }
+    vec3 f(vec3 outW, vec3 inW) const {
+        vec3 in = world2local(inW), out = world2local(outW);
+        bool reflect = dot(inW, n) * dot(outW, n) > 0;
+        vec3 r{0.f, 0.f, 0.f};
+        if (reflect) r = r + lobe.f(out, in);
+        return r;
+    }
+    float pdf(vec3 outW, vec3 inW) const {
+        vec3 out = world2local(outW), in = world2local(inW);
+        float p = 0.f;
+        p += lobe.pdf(out, in);
+        p /= 1.0f;
+        return p;
+    }
+    vec3 sample(vec3 outW, vec2 u, vec3& inW, float& p) const {
+        p = 0.f;
+        int comp = std::min((int)std::floor(u.x * 1), 0);
+        vec2 uR = {u.x * 1 - comp, u.y};
+        vec3 wi, wo = world2local(outW);
+        vec3 fr = lobe.sampled(wo, uR, wi, p);
+        if (p == 0) return {0.f, 0.f, 0.f};
+        inW = local2world(wi);
+        return fr;
+    }
+};
+
+// ---------------------------------------------------------- distributions
+// src/samplers/Distributions.cpp:7-44
+struct Distribution1D {
+    std::vector<float> func, cdf;
+    float funcInt = 0;
+    Distribution1D() = default;
+    explicit Distribution1D(const std::vector<float>& data) : func(data) {
+        cdf.resize(data.size() + 1);
+        cdf[0] = 0.f;
+        size_t n = data.size();
+        for (size_t i = 1; i < cdf.size(); ++i) cdf[i] = cdf[i - 1] + func[i - 1] / (float)n;
+        funcInt = cdf[n];
+        if (funcInt == 0) {
+            for (size_t i = 1; i < cdf.size(); ++i) cdf[i] = (float)i / (float)n;
+        } else {
+            for (size_t i = 1; i < cdf.size(); ++i) cdf[i] /= funcInt;
+        }
+    }
+    int count() const { return (int)func.size(); }
+    float sampleContinuous(float u, float& pdf, int* off = nullptr) const {
+        int offset = findInterval((int)cdf.size(), [&](int i) { return cdf[i] <= u; });
+        if (off) *off = offset;
+        float du = u - cdf[offset];
+        if ((cdf[offset + 1] - cdf[offset]) > 0) du /= (cdf[offset + 1] - cdf[offset]);
+        pdf = func[offset] / funcInt;
+        return (offset + du) / count();
+    }
+};
+// src/samplers/Distributions.cpp:46-76
+struct Distribution2D {
+    std::vector<Distribution1D> cond;
+    Distribution1D marginal;
+    Distribution2D() = default;
+    Distribution2D(const std::vector<float>& data, int width, int height) {
+        std::vector<float> mf;
+        for (int v = 0; v < height; ++v) {
+            std::vector<float> line(data.begin() + (size_t)v * width, data.begin() + (size_t)(v + 1) * width);
+            cond.emplace_back(line);
+            mf.push_back(cond.back().funcInt);
+        }
+        marginal = Distribution1D(mf);
+    }
+    vec2 sampleContinuous(vec2 u, float& pdf) const {
+        float pdfs[2];
+        int v;
+        float d1 = marginal.sampleContinuous(u.y, pdfs[1], &v);
+        float d0 = cond[v].sampleContinuous(u.x, pdfs[0]);
+        pdf = pdfs[0] * pdfs[1];
+        return {d0, d1};
+    }
+    float pdf(vec2 p) const {
+        int iu = (int)clampf((float)int(p.x * cond[0].count()), 0.f, (float)(cond[0].count() - 1));
+        int iv = (int)clampf((float)int(p.y * marginal.count()), 0.f, (float)(marginal.count() - 1));
+        return cond[iv].func[iu] / marginal.funcInt;
+    }
+};
+
+// ----------------------------------------------------------------- lights
+// Bilinear RGBA32F fetch standing in for Mango's filterLinear(image, uv, 0)
+// (absent from the reference tree: build-defined; repeat wrap, texel centres
+// at +0.5).
+inline vec3 filterLinear(const float* img, int W, int H, vec2 uv) {
+    float x = uv.x * (float)W - 0.5f, y = uv.y * (float)H - 0.5f;
+    float fx0 = std::floor(x), fy0 = std::floor(y);
+    float fx = x - fx0, fy = y - fy0;
+    int x0 = (int)fx0, y0 = (int)fy0;
+    auto wrap = [](int i, int n) { i %= n; return i < 0 ? i + n : i; };
+    int xa = wrap(x0, W), xb = wrap(x0 + 1, W), ya = wrap(y0, H), yb = wrap(y0 + 1, H);
+    auto px = [&](int xx, int yy) {
+        const float* p = img + ((size_t)yy * W + xx) * 4;
+        return vec3{p[0], p[1], p[2]};
+    };
+    vec3 top = px(xa, ya) * (1.0f - fx) + px(xb, ya) * fx;
+    vec3 bot = px(xa, yb) * (1.0f - fx) + px(xb, yb) * fx;
+    return top * (1.0f - fy) + bot * fy;
+}
+
+enum LightType { LIGHT_POINT = 0, LIGHT_ENV = 3 };  // src/lights/LightSource.hpp:12-17
+
+struct Light {
+    int type = LIGHT_POINT;
+    vec3 pos{0, 0, 0};        // point: light2world * (0,0,0,1)
+    vec3 I{0, 0, 0};          // point intensity / env scale
+    std::vector<float> img;   // env: RGBA32F, row-major, W*H*4
+    int W = 0, H = 0;
+    Distribution2D dist;
+
+    bool isDelta() const { return type == LIGHT_POINT; }
+
+    // src/lights/EnvLight.cpp:8-26.  glm::mat3 is filled column-major from
+    // the literal, so (M*rgb).y = 0.3575761 r + 0.7151522 g + 0.1191920 b.
+    // The table image is (H wide, W high) and is written at (y, x).
+    void buildEnv() {
+        std::vector<float> table((size_t)W * H);
+        for (int y = 0; y < H; ++y) {
+            float sinTheta = std::sin((float)M_PI * (y + .5f) / (float)H);
+            for (int x = 0; x < W; ++x) {
+                const float* c = &img[((size_t)y * W + x) * 4];
+                float lum = 0.3575761f * c[0] + 0.7151522f * c[1] + 0.1191920f * c[2];
+                table[(size_t)x * H + y] = sinTheta * lum;
+            }
+        }
+        dist = Distribution2D(table, H, W);
+    }
+    // src/lights/PointLight.cpp:14-18, src/lights/EnvLight.cpp:28-43
+    vec3 sampleLi(const Vertex& vtx, vec2 u, vec3& in, float& pdf) const {
+        if (type == LIGHT_POINT) {
+            in = normalize(pos - vtx.pos);
+            pdf = 1.f;
+            return I / length2(pos - vtx.pos);
+        }
+        float mapPdf;
+        vec2 uv = dist.sampleContinuous(u, mapPdf);
+        pdf = 0.0f;
+        if (mapPdf == 0) return {0.f, 0.f, 0.f};
+        float theta = uv.x * (float)M_PI, phi = uv.y * 2.f * (float)M_PI;
+        float cosT = std::cos(theta), sinT = std::sin(theta);
+        float sinP = std::sin(phi), cosP = std::cos(phi);
+        in = {sinT * cosP, sinT * sinP, cosT};
+        pdf = mapPdf / (2 * (float)M_PI * (float)M_PI * sinT);
+        if (!std::isfinite(pdf)) pdf = 0.0f;
+        return filterLinear(img.data(), W, H, uv) * I;
+    }
+    // src/lights/PointLight.cpp:20-22, src/lights/EnvLight.cpp:45-52
+    float pdfLi(const Vertex&, vec3 inW) const {
+        if (type == LIGHT_POINT) return 1.0f;
+        float theta = sphericalTheta(inW), phi = sphericalPhi(inW);
+        float sinT = std::sin(theta);
+        if (sinT == 0) return 0;
+        return dist.pdf({phi * INV_2PI, theta * INV_PI}) / (2 * (float)M_PI * (float)M_PI * sinT);
+    }
+    // src/lights/LightSource.hpp:28-30, src/lights/EnvLight.cpp:60-65
+    vec3 le(const Ray& ray) const {
+        if (type == LIGHT_POINT) return {0.f, 0.f, 0.f};
+        vec3 w = normalize(ray.dir);
+        vec2 st = {sphericalPhi(w) * INV_2PI, sphericalTheta(w) * INV_PI};
+        return filterLinear(img.data(), W, H, st);
+    }
+};
+
+struct MaterialData {
+    vec3 diffuseColor{1, 1, 1};
+    float roughness = 0.5f;  // src/scene/Material.cpp:9
+};
+
+struct Camera {
+    vec3 pos, right, up, forward;  // src/cpu/Integrator.cpp:85-92
+};
+
+// ------------------------------------------------------------- integrator
+struct Scene {
+    BVH bvh;
+    std::vector<MaterialData> materials;  // one per model
+    std::vector<Light> lights;
+    bool haveFrame = true;
+};
+
+struct RenderCounters {
+    std::atomic<uint64_t> closest{0}, shadow{0};
+};
+
+// Random-number slots of one path vertex at depth d with L lights: per
+// light 2 (light sample) + 2 (the BSDF sample of the non-delta branch), then
+// 2 for the bounce.  Fixed slots so that a skipped draw does not shift later
+// ones.
+inline uint32_t dim_light(int d, int L, int l, int k) { return (uint32_t)(d * (4 * L + 2) + 4 * l + k); }
+inline uint32_t dim_bounce(int d, int L, int k) { return (uint32_t)(d * (4 * L + 2) + 4 * L + k); }
+
+// src/cpu/PathTracer.cpp:43-52
+inline Ray cameraRay(const Camera& cam, int x, int y, int W, int H) {
+    float ni = ((float)x / (float)W) - 0.5f;
+    float nj = ((float)y / (float)H) - 0.5f;
+    nj = -nj;
+    nj *= ((float)H / (float)W);
+    vec3 ip = ni * cam.right + nj * cam.up + cam.forward;
+    return Ray(cam.pos, normalize(ip));
+}
+
+// src/scene/Material.cpp:214-225 without a texture: colour = (255/255) * diffuseColor
+inline BSDF computeBSDF(const Scene& s, const Vertex& v, int model) {
+    const MaterialData& m = s.materials[model];
+    vec3 c = V3(255.0f) / 255.0f;
+    c = c * m.diffuseColor;
+    return BSDF(v, Diffuse(c, m.roughness));
+}
+
+// One pixel of src/cpu/PathTracer.cpp:36-160.  `frames` = passes already
+// accumulated; film is W*H RGBA32F, updated in place (the reference's
+// ping-pong pair reads the previous value of the same pixel only).
+inline void renderPixel(const Scene& s, const Camera& cam, int x, int y, int W, int H, int maxDepth,
+                        uint64_t seed, uint32_t pass, float frames, float* film, RenderCounters* rc) {
+    const int L = (int)s.lights.size();
+    const uint32_t pixel = (uint32_t)(y * W + x);
+    float* out4 = film + (size_t)pixel * 4;
+    Ray ray = cameraRay(cam, x, y, W, H);
+    uint64_t nClosest = 1, nShadow = 0;
+    RayHit hit = s.bvh.intersect(ray);
+    if (!hit.status) {
+        vec3 Lm{0.f, 0.f, 0.f};
+        for (const Light& l : s.lights) Lm = Lm + l.le(ray);
+        out4[0] = Lm.x; out4[1] = Lm.y; out4[2] = Lm.z; out4[3] = 1.0f;
+        if (rc) rc->closest += nClosest;
+        return;
+    }
+    Vertex vertex = s.bvh.postIntersect(ray, hit, s.haveFrame);
+    BSDF bsdf = computeBSDF(s, vertex, hit.id0);
+    vec3 out = -ray.dir;
+    vec3 pixelColor{0.f, 0.f, 0.f};
+    vec3 threshold{1.f, 1.f, 1.f};
+    for (int d = 0; d < maxDepth; ++d) {
+        for (int li_ = 0; li_ < L; ++li_) {
+            const Light& light = s.lights[li_];
+            vec3 in{0.f, 0.f, 0.f};
+            float lightPdf;
+            vec2 u = {rng_u01(seed, pixel, pass, dim_light(d, L, li_, 0)),
+                      rng_u01(seed, pixel, pass, dim_light(d, L, li_, 1))};
+            vec3 li = light.sampleLi(vertex, u, in, lightPdf);
+            if (lightPdf == 0.0f) continue;
+            nShadow++;
+            RayHit shadowHit = s.bvh.occluded(Ray(vertex.pos, in));
+            if (shadowHit.status) continue;
+            vec3 bsdfColor = bsdf.f(out, in);
+            float bsdfPdf = bsdf.pdf(out, in);
+            if (light.isDelta()) {
+                pixelColor = pixelColor + threshold * bsdfColor * li / lightPdf;
+            } else {
+                pixelColor = pixelColor + threshold * bsdfColor * li * powerHeuristic(1, lightPdf, 1, bsdfPdf) / lightPdf;
+                vec3 inBSDF;
+                vec2 u2 = {rng_u01(seed, pixel, pass, dim_light(d, L, li_, 2)),
+                           rng_u01(seed, pixel, pass, dim_light(d, L, li_, 3))};
+                vec3 f = bsdf.sample(out, u2, inBSDF, bsdfPdf);
+                if (bsdfPdf == 0.0f) continue;
+                f = f * std::fabs(dot(in, vertex.normal));
+                float weight = 1.f;
+                lightPdf = light.pdfLi(vertex, in);
+                if (lightPdf == 0.0f) continue;
+                weight = powerHeuristic(1, bsdfPdf, 1, lightPdf);
+                vec3 li2 = light.le(ray);
+                if (!is_zero(li2)) pixelColor = pixelColor + f * li2 * weight / bsdfPdf;
+            }
+        }
+        vec3 nextDir{0.f, 0.f, 0.f};
+        float nextPDF = 0.0f;
+        vec2 u3 = {rng_u01(seed, pixel, pass, dim_bounce(d, L, 0)), rng_u01(seed, pixel, pass, dim_bounce(d, L, 1))};
+        vec3 bsdfColor = bsdf.sample(out, u3, nextDir, nextPDF);
+        if (is_zero(bsdfColor) || nextPDF == 0.0f) break;
+        threshold = threshold * (bsdfColor * std::fabs(dot(nextDir, vertex.normal)) / nextPDF);
+        ray = Ray(vertex.pos, nextDir);
+        nClosest++;
+        hit = s.bvh.intersect(ray);
+        if (hit.status) {
+            vertex = s.bvh.postIntersect(ray, hit, s.haveFrame);
+            bsdf = computeBSDF(s, vertex, hit.id0);
+            out = -ray.dir;
+        } else {
+            break;
+        }
+    }
+    if (frames != 0.0f) {
+        vec3 prev{out4[0], out4[1], out4[2]};
+        prev = prev * frames;
+        prev = prev + pixelColor;
+        prev = prev / (frames + 1.f);
+        out4[0] = prev.x; out4[1] = prev.y; out4[2] = prev.z; out4[3] = 1.0f;
+    } else {
+        out4[0] = pixelColor.x; out4[1] = pixelColor.y; out4[2] = pixelColor.z; out4[3] = 1.0f;
+    }
+    if (rc) { rc->closest += nClosest; rc->shadow += nShadow; }
+}
+
+// One sample pass over the film: src/cpu/Integrator.cpp:26-67 (64x64 tiles
+// pulled from an atomic counter by `threads` workers; the tile grid uses the
+// height for its y extent, where the reference's width only adds empty tiles).
+inline void renderPass(const Scene& s, const Camera& cam, int W, int H, int maxDepth, uint64_t seed,
+                       uint32_t pass, float frames, float* film, int threads, RenderCounters* rc) {
+    const int tileSize = 64;
+    int tx = (W + tileSize - 1) / tileSize, ty = (H + tileSize - 1) / tileSize;
+    std::atomic<int> tileCurr{0};
+    int tileCount = tx * ty;
+    auto worker = [&]() {
+        for (;;) {
+            int t = tileCurr++;
+            if (t >= tileCount) break;
+            int sx = (t % tx) * tileSize, sy = (t / tx) * tileSize;
+            for (int y = sy; y < sy + tileSize && y < H; ++y)
+                for (int x = sx; x < sx + tileSize && x < W; ++x)
+                    renderPixel(s, cam, x, y, W, H, maxDepth, seed, pass, frames, film, rc);
+        }
+    };
+    if (threads <= 1) { worker(); return; }
+    std::vector<std::thread> pool;
+    for (int i = 0; i < threads; ++i) pool.emplace_back(worker);
+    for (auto& t : pool) t.join();
+}
+
+}  // namespace orc

@@ -1,0 +1,261 @@
+"""ctypes binding of librt_hip.so (the C-ABI in include/rt_hip.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an
+exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .scenes import LIGHT_ENV, Camera, Scene
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_hip.so")
+_lib = None
+
+
+class RtError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"rt_hip error {code}: {msg}")
+        self.code = code
+
+
+class rt_material(C.Structure):
+    _fields_ = [("diffuse_color", C.c_float * 3), ("roughness", C.c_float)]
+
+
+class rt_light(C.Structure):
+    _fields_ = [("type", C.c_int32), ("pos", C.c_float * 3), ("intensity", C.c_float * 3),
+                ("env_rgba", C.POINTER(C.c_float)), ("env_w", C.c_int32), ("env_h", C.c_int32)]
+
+
+class rt_scene_desc(C.Structure):
+    _fields_ = [("n_vertices", C.c_uint32),
+                ("pos", C.POINTER(C.c_float)), ("pos_stride", C.c_uint32),
+                ("normal", C.POINTER(C.c_float)), ("normal_stride", C.c_uint32),
+                ("uv", C.POINTER(C.c_float)), ("uv_stride", C.c_uint32),
+                ("tangent", C.POINTER(C.c_float)), ("tangent_stride", C.c_uint32),
+                ("binormal", C.POINTER(C.c_float)), ("binormal_stride", C.c_uint32),
+                ("n_indices", C.c_uint32), ("indices", C.POINTER(C.c_uint32)),
+                ("tri_model", C.POINTER(C.c_int32)),
+                ("n_models", C.c_uint32), ("materials", C.POINTER(rt_material)),
+                ("n_lights", C.c_uint32), ("lights", C.POINTER(rt_light))]
+
+
+class rt_params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_depth", C.c_int32), ("tile_size", C.c_int32),
+                ("seed", C.c_uint64), ("device", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
+                ("max_rays", C.c_uint32)]
+
+
+class rt_stats(C.Structure):
+    _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("passes", C.c_uint64),
+                ("n_nodes", C.c_uint32), ("n_triangles", C.c_uint32), ("bvh_max_depth", C.c_int32),
+                ("n_local_pixels", C.c_uint32), ("last_trace_ms", C.c_float), ("last_render_ms", C.c_float),
+                ("bvh_build_ms", C.c_float)]
+
+
+EXPORTS = [
+    "rt_create", "rt_destroy", "rt_last_error", "rt_set_camera", "rt_reset_accumulation", "rt_render",
+    "rt_read_film", "rt_film_slab", "rt_copy_film_slab", "rt_unpack_slabs", "rt_trace_closest",
+    "rt_trace_occluded", "rt_trace_closest_dev", "rt_trace_occluded_dev", "rt_get_bvh", "rt_get_stats",
+    "rt_synchronize", "rt_version", "rt_lbvh_host", "rt_morton3d",
+]
+
+
+def load_library():
+    """Loads librt_hip.so; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise RuntimeError(f"{_LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
+                           "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(_LIB_PATH)
+    vp, fp, ip, up = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
+    lib.rt_create.argtypes = [C.POINTER(rt_scene_desc), C.POINTER(rt_params), C.POINTER(vp)]
+    lib.rt_destroy.argtypes = [vp]
+    lib.rt_destroy.restype = None
+    lib.rt_last_error.argtypes = [vp]
+    lib.rt_last_error.restype = C.c_char_p
+    lib.rt_set_camera.argtypes = [vp, fp, fp, fp, fp]
+    lib.rt_reset_accumulation.argtypes = [vp]
+    lib.rt_render.argtypes = [vp, C.c_uint32]
+    lib.rt_read_film.argtypes = [vp, fp]
+    lib.rt_film_slab.argtypes = [vp, C.POINTER(vp), up, C.POINTER(C.c_uint64)]
+    lib.rt_copy_film_slab.argtypes = [vp, vp, C.c_uint64]
+    lib.rt_unpack_slabs.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, C.c_uint64, fp]
+    lib.rt_trace_closest.argtypes = [vp, C.c_uint32, fp, fp, ip, ip, fp, fp]
+    lib.rt_trace_occluded.argtypes = [vp, C.c_uint32, fp, ip]
+    lib.rt_trace_closest_dev.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint32]
+    lib.rt_trace_occluded_dev.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32]
+    lib.rt_get_bvh.argtypes = [vp, up, fp, ip, ip, ip, ip, ip]
+    lib.rt_get_stats.argtypes = [vp, C.POINTER(rt_stats)]
+    lib.rt_synchronize.argtypes = [vp]
+    lib.rt_version.restype = C.c_char_p
+    lib.rt_lbvh_host.argtypes = [fp, C.c_uint32, up, C.c_uint32, ip, ip, fp, ip, ip, ip, ip, ip]
+    lib.rt_morton3d.argtypes = [C.c_float, C.c_float, C.c_float]
+    for name in EXPORTS:
+        if name not in ("rt_destroy", "rt_last_error", "rt_version", "rt_morton3d"):
+            getattr(lib, name).restype = C.c_int
+    lib.rt_morton3d.restype = C.c_uint32
+    _lib = lib
+    return lib
+
+
+def _fptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _iptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class Context:
+    """One rt_ctx: a scene resident on one MI355X plus this rank's share of the film."""
+
+    def __init__(self, scene: Scene, width: int, height: int, max_depth: int = 4, seed: int = 0, device: int = 0,
+                 rank: int = 0, world: int = 1, tile_size: int = 64, use_frame: bool = True):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.width, self.height, self.world, self.rank, self.tile_size = width, height, world, rank, tile_size
+        s = scene
+        self._keep = [s.pos, s.normal, s.uv, s.tangent, s.binormal, s.indices, s.tri_model]
+        mats = (rt_material * s.n_models)()
+        for m in range(s.n_models):
+            mats[m].diffuse_color[:] = [float(x) for x in s.materials[m, :3]]
+            mats[m].roughness = float(s.materials[m, 3])
+        lights = (rt_light * max(1, len(s.lights)))()
+        for i, l in enumerate(s.lights):
+            lights[i].type = l.type
+            lights[i].pos[:] = [float(x) for x in l.pos]
+            lights[i].intensity[:] = [float(x) for x in l.intensity]
+            if l.type == LIGHT_ENV:
+                env = np.ascontiguousarray(l.env, np.float32)
+                self._keep.append(env)
+                lights[i].env_rgba = _fptr(env)
+                lights[i].env_h, lights[i].env_w = env.shape[0], env.shape[1]
+        d = rt_scene_desc()
+        d.n_vertices = s.pos.shape[0]
+        d.pos, d.pos_stride = _fptr(s.pos), 12
+        d.normal, d.normal_stride = _fptr(s.normal), 12
+        d.uv, d.uv_stride = _fptr(s.uv), 8
+        if use_frame:
+            d.tangent, d.tangent_stride = _fptr(s.tangent), 12
+            d.binormal, d.binormal_stride = _fptr(s.binormal), 12
+        d.n_indices = s.indices.size
+        d.indices = s.indices.ctypes.data_as(C.POINTER(C.c_uint32))
+        d.tri_model = _iptr(s.tri_model)
+        d.n_models, d.materials = s.n_models, mats
+        d.n_lights, d.lights = len(s.lights), lights
+        p = rt_params(width, height, max_depth, tile_size, seed, device, rank, world, 0)
+        rc = self._lib.rt_create(C.byref(d), C.byref(p), C.byref(self._h))
+        if rc != 0:
+            raise RtError(rc, self._lib.rt_last_error(None).decode())
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise RtError(rc, self._lib.rt_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._lib.rt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- integrator path
+    def set_camera(self, cam: Camera):
+        a = [np.ascontiguousarray(v, np.float32) for v in (cam.pos, cam.right, cam.up, cam.forward)]
+        self._check(self._lib.rt_set_camera(self._h, *[_fptr(v) for v in a]))
+
+    def reset_accumulation(self):
+        self._check(self._lib.rt_reset_accumulation(self._h))
+
+    def render(self, n_passes: int = 1):
+        self._check(self._lib.rt_render(self._h, n_passes))
+
+    def read_film(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._lib.rt_read_film(self._h, _fptr(out)))
+        return out
+
+    def film_slab_info(self) -> Tuple[int, int, int]:
+        ptr, nt, nf = C.c_void_p(), C.c_uint32(), C.c_uint64()
+        self._check(self._lib.rt_film_slab(self._h, C.byref(ptr), C.byref(nt), C.byref(nf)))
+        return int(ptr.value or 0), int(nt.value), int(nf.value)
+
+    def copy_film_slab(self, device_ptr: int, n_floats: int):
+        self._check(self._lib.rt_copy_film_slab(self._h, C.c_void_p(device_ptr), n_floats))
+
+    # ---- BVH hooks
+    def trace_closest(self, rays: np.ndarray):
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[1]
+        t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
+        id0 = np.empty(n, np.int32); id1 = np.empty(n, np.int32)
+        self._check(self._lib.rt_trace_closest(self._h, n, _fptr(rays), _fptr(t), _iptr(id0), _iptr(id1), _fptr(u), _fptr(v)))
+        return t, id0, id1, u, v
+
+    def trace_occluded(self, rays: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[1]
+        st = np.empty(n, np.int32)
+        self._check(self._lib.rt_trace_occluded(self._h, n, _fptr(rays), _iptr(st)))
+        return st
+
+    def trace_closest_dev(self, n: int, d_rays: int, d_t: int, d_id0: int, d_id1: int, d_u: int, d_v: int, repeat: int = 1):
+        self._check(self._lib.rt_trace_closest_dev(self._h, n, d_rays, d_t, d_id0, d_id1, d_u, d_v, repeat))
+
+    def trace_occluded_dev(self, n: int, d_rays: int, d_status: int, repeat: int = 1):
+        self._check(self._lib.rt_trace_occluded_dev(self._h, n, d_rays, d_status, repeat))
+
+    def get_bvh(self):
+        n = C.c_uint32()
+        self._check(self._lib.rt_get_bvh(self._h, C.byref(n), None, None, None, None, None, None))
+        n = n.value
+        boxes = np.empty((n, 6), np.float32)
+        arrs = [np.empty(n, np.int32) for _ in range(5)]
+        nn = C.c_uint32()
+        self._check(self._lib.rt_get_bvh(self._h, C.byref(nn), _fptr(boxes), *[_iptr(a) for a in arrs]))
+        return (boxes, *arrs)
+
+    def stats(self) -> dict:
+        st = rt_stats()
+        self._check(self._lib.rt_get_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in rt_stats._fields_}
+
+    def synchronize(self):
+        self._check(self._lib.rt_synchronize(self._h))
+
+
+def unpack_slabs(width: int, height: int, tile_size: int, world: int, slabs: np.ndarray, per_rank: int) -> np.ndarray:
+    lib = load_library()
+    slabs = np.ascontiguousarray(slabs, np.float32)
+    out = np.empty((height, width, 4), np.float32)
+    rc = lib.rt_unpack_slabs(width, height, tile_size, world, _fptr(slabs), per_rank, _fptr(out))
+    if rc != 0:
+        raise RtError(rc, "rt_unpack_slabs failed")
+    return out
+
+
+def lbvh_host(scene: Scene):
+    """Runs the library's host LBVH builder without a device: (max_depth,
+    boxes, left, right, tri, model, leaf) in the reference's node numbering."""
+    lib = load_library()
+    n = 2 * scene.n_triangles - 1
+    boxes = np.empty((n, 6), np.float32)
+    arrs = [np.empty(n, np.int32) for _ in range(5)]
+    md = C.c_int32()
+    rc = lib.rt_lbvh_host(_fptr(scene.pos), 12, scene.indices.ctypes.data_as(C.POINTER(C.c_uint32)), scene.indices.size,
+                          _iptr(scene.tri_model), C.byref(md), _fptr(boxes), *[_iptr(a) for a in arrs])
+    if rc != 0:
+        raise RtError(rc, "rt_lbvh_host failed")
+    return (md.value, boxes, *arrs)

@@ -1,0 +1,710 @@
+// C-ABI of the gfx950 path-tracing core (declared in include/rt_hip.h):
+// context, scene upload, the per-pass wavefront schedule, film read-back.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+#include "lbvh_host.h"
+#include "shade.h"
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct EnvTables {
+    float4* img = nullptr;
+    float *cond_func = nullptr, *cond_cdf = nullptr, *cond_int = nullptr, *marg_cdf = nullptr;
+};
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::string err;
+
+    rt_params params{};
+    int tile = 64, tiles_x = 0, tiles_y = 0;
+    uint32_t n_local_tiles = 0, n_slots = 0, n_valid = 0;
+
+    // geometry
+    LbvhResult bvh;
+    float4* d_nodes = nullptr;
+    float4* d_tris = nullptr;
+    int32_t* d_ovf = nullptr;
+    TraceScene ts{};
+    uint32_t grid_trace = 0;
+
+    // shading
+    float* d_tri_attr = nullptr;
+    float4* d_materials = nullptr;
+    DevLight* d_lights = nullptr;
+    std::vector<EnvTables> env;
+    ShadeScene ss{};
+    int n_lights = 0;
+
+    // path state
+    std::vector<void*> allocs;
+    PathBuffers pb{};
+    uint32_t* d_q0 = nullptr;
+    uint32_t* d_q[2] = {nullptr, nullptr};
+    uint32_t* d_counts = nullptr;       // [max_depth+1] queue counts, then [max_depth][L] shadow counts
+    uint32_t* d_counts_init = nullptr;  // template copied in at the start of a pass
+    uint32_t n_counts = 0;
+    ShadowQueue* d_sq = nullptr;
+    std::vector<ShadowQueue> h_sq;
+    unsigned long long* d_raystats = nullptr;  // [0] closest, [1] shadow
+    uint32_t* d_slot_pixel = nullptr;
+    std::vector<uint32_t> h_slot_pixel;
+
+    // camera / accumulation
+    CameraK cam{};
+    bool have_camera = false;
+    uint64_t frames = 0;
+
+    // rt_trace_* staging (host-pointer variants)
+    float* d_tr_rays = nullptr;
+    float* d_tr_out = nullptr;  // t,u,v planes + id0,id1 planes
+    uint32_t tr_cap = 0;
+
+    float last_trace_ms = 0.f, last_render_ms = 0.f, bvh_build_ms = 0.f;
+};
+
+namespace {
+
+#define HIP_TRY(ctx, call)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            char b_[512];                                                                      \
+            snprintf(b_, sizeof b_, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            (ctx)->err = b_;                                                                   \
+            return RT_ERR_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+template <typename T>
+int dev_alloc(rt_ctx* c, T** p, size_t count) {
+    void* q = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) {
+        char b[256];
+        snprintf(b, sizeof b, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+        c->err = b;
+        return RT_ERR_HIP;
+    }
+    c->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return RT_OK;
+}
+
+template <typename T>
+int dev_upload(rt_ctx* c, T** p, const T* host, size_t count) {
+    int r = dev_alloc(c, p, count);
+    if (r) return r;
+    if (count) HIP_TRY(c, hipMemcpy(*p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+inline const float* strided(const float* base, uint32_t stride, uint32_t i) {
+    return reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)i * stride);
+}
+
+// Distribution1D's constructor, src/samplers/Distributions.cpp:7-22
+float build_cdf(const float* func, int n, float* cdf) {
+    cdf[0] = 0.f;
+    for (int i = 1; i <= n; ++i) cdf[i] = cdf[i - 1] + func[i - 1] / (float)n;
+    float func_int = cdf[n];
+    if (func_int == 0) {
+        for (int i = 1; i <= n; ++i) cdf[i] = (float)i / (float)n;
+    } else {
+        for (int i = 1; i <= n; ++i) cdf[i] /= func_int;
+    }
+    return func_int;
+}
+
+// EnvLight's constructor, src/lights/EnvLight.cpp:8-26.  The glm::mat3 there
+// is filled column-major from a row-major literal, so the luminance row it
+// applies is (0.3575761, 0.7151522, 0.1191920); the table image is H wide
+// and W high, written at (y, x), and handed to Distribution2D as W rows of H.
+int build_env(rt_ctx* c, const rt_light& src, DevLight& dst, EnvTables& tab) {
+    const int W = src.env_w, H = src.env_h;
+    if (!src.env_rgba || W < 2 || H < 2) {
+        c->err = "env light needs an image of at least 2x2";
+        return RT_ERR_ARG;
+    }
+    std::vector<float> table((size_t)W * H), cdf((size_t)W * (H + 1)), cint(W), mcdf(W + 1);
+    for (int y = 0; y < H; ++y) {
+        float sinTheta = std::sin((float)M_PI * (y + .5f) / (float)H);
+        for (int x = 0; x < W; ++x) {
+            const float* px = src.env_rgba + ((size_t)y * W + x) * 4;
+            float lum = 0.3575761f * px[0] + 0.7151522f * px[1] + 0.1191920f * px[2];
+            table[(size_t)x * H + y] = sinTheta * lum;
+        }
+    }
+    for (int v = 0; v < W; ++v) cint[v] = build_cdf(&table[(size_t)v * H], H, &cdf[(size_t)v * (H + 1)]);
+    float mint = build_cdf(cint.data(), W, mcdf.data());
+    int r;
+    if ((r = dev_upload(c, &tab.img, reinterpret_cast<const float4*>(src.env_rgba), (size_t)W * H))) return r;
+    if ((r = dev_upload(c, &tab.cond_func, table.data(), table.size()))) return r;
+    if ((r = dev_upload(c, &tab.cond_cdf, cdf.data(), cdf.size()))) return r;
+    if ((r = dev_upload(c, &tab.cond_int, cint.data(), cint.size()))) return r;
+    if ((r = dev_upload(c, &tab.marg_cdf, mcdf.data(), mcdf.size()))) return r;
+    dst.W = W; dst.H = H;
+    dst.img = tab.img;
+    dst.cond_func = tab.cond_func; dst.cond_cdf = tab.cond_cdf; dst.cond_int = tab.cond_int;
+    dst.marg_cdf = tab.marg_cdf; dst.marg_int = mint;
+    return RT_OK;
+}
+
+uint32_t grid_for(const rt_ctx* c, uint32_t n) {
+    uint32_t g = (n + RT_BLOCK - 1) / RT_BLOCK;
+    if (g > c->grid_trace) g = c->grid_trace;
+    return g ? g : 1;
+}
+
+int ensure_trace_staging(rt_ctx* c, uint32_t n) {
+    if (n <= c->tr_cap) return RT_OK;
+    // grow-only staging for the host-pointer entry points
+    int r;
+    if ((r = dev_alloc(c, &c->d_tr_rays, (size_t)n * 6))) return r;
+    if ((r = dev_alloc(c, &c->d_tr_out, (size_t)n * 5))) return r;
+    c->tr_cap = n;
+    return RT_OK;
+}
+
+int launch_closest(rt_ctx* c, uint32_t n, const float* d_rays, float* d_t, int32_t* d_id0, int32_t* d_id1, float* d_u,
+                   float* d_v, uint32_t repeat) {
+    if (repeat == 0) repeat = 1;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    for (uint32_t r = 0; r < repeat; ++r)
+        hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(c, n)), dim3(RT_BLOCK), 0, c->stream, c->ts, d_rays, n, nullptr, nullptr,
+                           n, d_t, d_id0, d_id1, d_u, d_v, c->d_raystats);
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_trace_ms = ms / (float)repeat;
+    return RT_OK;
+}
+
+int launch_occluded(rt_ctx* c, uint32_t n, const float* d_rays, int32_t* d_status, uint32_t repeat) {
+    if (repeat == 0) repeat = 1;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    for (uint32_t r = 0; r < repeat; ++r)
+        hipLaunchKernelGGL(k_trace_occluded, dim3(grid_for(c, n)), dim3(RT_BLOCK), 0, c->stream, c->ts, d_rays, n, n, d_status);
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    c->last_trace_ms = ms / (float)repeat;
+    return RT_OK;
+}
+
+// One sample pass: the GPU form of Integrator::update (src/cpu/Integrator.cpp:26-67).
+int run_pass(rt_ctx* c) {
+    const int D = c->params.max_depth, L = c->n_lights;
+    const uint32_t n = c->n_slots;
+    const uint32_t pass = (uint32_t)c->frames;
+    const uint64_t seed_mixed = [&] {
+        uint64_t z = c->params.seed + 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }();
+    HIP_TRY(c, hipMemcpyAsync(c->d_counts, c->d_counts_init, c->n_counts * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    const uint32_t gslots = (n + RT_BLOCK - 1) / RT_BLOCK;
+    hipLaunchKernelGGL(k_generate, dim3(gslots), dim3(RT_BLOCK), 0, c->stream, c->pb, c->cam);
+    const uint32_t gtrace = grid_for(c, c->n_valid);
+    const uint32_t gshade = std::min<uint32_t>(gslots, (uint32_t)c->num_cu * 8u);
+    const uint32_t* qin = c->d_q0;
+    for (int d = 0; d < D; ++d) {
+        uint32_t* cnt_in = c->d_counts + d;
+        uint32_t* cnt_out = c->d_counts + d + 1;
+        uint32_t* qout = c->d_q[d & 1];
+        hipLaunchKernelGGL(k_trace_closest, dim3(gtrace), dim3(RT_BLOCK), 0, c->stream, c->ts, c->pb.rays, n, qin, cnt_in, 0u,
+                           c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v, c->d_raystats);
+        uint32_t* sqc = c->d_counts + (D + 1) + (size_t)d * L;
+        hipLaunchKernelGGL(k_shade, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, c->pb, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
+                           qout, cnt_out, c->d_sq, sqc);
+        for (int l = 0; l < L; ++l)
+            hipLaunchKernelGGL(k_shadow, dim3(gtrace), dim3(RT_BLOCK), 0, c->stream, c->ts, c->pb, c->h_sq[l], sqc + l,
+                               c->d_raystats + 1);
+        qin = qout;
+    }
+    hipLaunchKernelGGL(k_film, dim3(gslots), dim3(RT_BLOCK), 0, c->stream, c->pb, (float)c->frames);
+    HIP_TRY(c, hipGetLastError());
+    c->frames++;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_version(void) { return "rt_hip 0.1 gfx950"; }
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) {
+    if (!sd->pos || !sd->indices || !sd->tri_model || sd->n_indices < 3 || sd->n_indices % 3 != 0 || sd->n_vertices == 0) {
+        c->err = "scene needs positions, indices (a multiple of 3, at least one triangle) and tri_model";
+        return RT_ERR_ARG;
+    }
+    if (!sd->normal || !sd->materials || sd->n_models == 0) {
+        c->err = "scene needs normals and at least one material";
+        return RT_ERR_ARG;
+    }
+    if ((sd->tangent == nullptr) != (sd->binormal == nullptr)) {
+        c->err = "tangent and binormal must both be given or both be null";
+        return RT_ERR_ARG;
+    }
+    if (pr->width <= 0 || pr->height <= 0 || pr->max_depth <= 0 || pr->max_depth > 64) {
+        c->err = "width, height must be positive and max_depth in 1..64";
+        return RT_ERR_ARG;
+    }
+    if ((uint64_t)pr->width * (uint64_t)pr->height >= 0xFFFFFFFFull) {
+        c->err = "film too large";
+        return RT_ERR_LIMIT;
+    }
+    c->params = *pr;
+    c->tile = pr->tile_size > 0 ? pr->tile_size : 64;
+    if (c->tile % 8 != 0) {
+        c->err = "tile_size must be a multiple of 8";
+        return RT_ERR_ARG;
+    }
+    const int world = pr->world > 0 ? pr->world : 1;
+    const int rank = pr->rank;
+    if (rank < 0 || rank >= world) {
+        c->err = "rank must be in [0, world)";
+        return RT_ERR_ARG;
+    }
+    const uint32_t T = sd->n_indices / 3;
+    for (uint32_t i = 0; i < sd->n_indices; ++i)
+        if (sd->indices[i] >= sd->n_vertices) {
+            c->err = "index out of range";
+            return RT_ERR_ARG;
+        }
+    for (uint32_t t = 0; t < T; ++t)
+        if (sd->tri_model[t] < 0 || (uint32_t)sd->tri_model[t] >= sd->n_models) {
+            c->err = "tri_model out of range";
+            return RT_ERR_ARG;
+        }
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        c->err = "no HIP device available";
+        return RT_ERR_NO_DEVICE;
+    }
+    if (pr->device < 0 || pr->device >= ndev) {
+        c->err = "device ordinal out of range";
+        return RT_ERR_ARG;
+    }
+    c->device = pr->device;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipEventCreate(&c->ev0));
+    HIP_TRY(c, hipEventCreate(&c->ev1));
+
+    // ---- BVH
+    auto t0 = std::chrono::steady_clock::now();
+    build_lbvh(sd->pos, sd->pos_stride ? sd->pos_stride : 12, sd->indices, sd->n_indices, sd->tri_model, c->bvh);
+    c->bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    int r;
+    if ((r = dev_upload(c, &c->d_nodes, reinterpret_cast<const float4*>(c->bvh.nodes.data()), c->bvh.nodes.size() * 4))) return r;
+    if ((r = dev_upload(c, &c->d_tris, reinterpret_cast<const float4*>(c->bvh.tris.data()), c->bvh.tris.size() * 3))) return r;
+
+    int bpc = 0;
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_closest, RT_BLOCK, 0));
+    if (bpc < 1) bpc = 1;
+    if (bpc > 8) bpc = 8;
+    c->grid_trace = (uint32_t)c->num_cu * (uint32_t)bpc;
+    const uint32_t ovf_levels = (uint32_t)std::max(1, c->bvh.max_depth + 2 - RT_STACK_LDS);
+    const uint32_t ovf_stride = c->grid_trace * RT_BLOCK;
+    if ((r = dev_alloc(c, &c->d_ovf, (size_t)ovf_levels * ovf_stride))) return r;
+    c->ts.nodes = c->d_nodes;
+    c->ts.tris = c->d_tris;
+    c->ts.root_link = c->bvh.root_link;
+    for (int k = 0; k < 3; ++k) { c->ts.rmin[k] = c->bvh.root_min[k]; c->ts.rmax[k] = c->bvh.root_max[k]; }
+    c->ts.ovf = c->d_ovf;
+    c->ts.ovf_stride = ovf_stride;
+    c->ts.ovf_levels = ovf_levels;
+
+    // ---- shading tables: per-triangle attribute blocks, 3 x (normal uv tangent binormal)
+    {
+        std::vector<float> attr((size_t)T * 36, 0.f);
+        const bool frame = sd->tangent && sd->binormal;
+        for (uint32_t t = 0; t < T; ++t)
+            for (int v = 0; v < 3; ++v) {
+                uint32_t vi = sd->indices[3 * t + v];
+                float* a = &attr[(size_t)t * 36 + v * 11];
+                const float* nn = strided(sd->normal, sd->normal_stride ? sd->normal_stride : 12, vi);
+                a[0] = nn[0]; a[1] = nn[1]; a[2] = nn[2];
+                if (sd->uv) {
+                    const float* uu = strided(sd->uv, sd->uv_stride ? sd->uv_stride : 8, vi);
+                    a[3] = uu[0]; a[4] = uu[1];
+                }
+                if (frame) {
+                    const float* tt = strided(sd->tangent, sd->tangent_stride ? sd->tangent_stride : 12, vi);
+                    const float* bb = strided(sd->binormal, sd->binormal_stride ? sd->binormal_stride : 12, vi);
+                    a[5] = tt[0]; a[6] = tt[1]; a[7] = tt[2];
+                    a[8] = bb[0]; a[9] = bb[1]; a[10] = bb[2];
+                }
+            }
+        if ((r = dev_upload(c, &c->d_tri_attr, attr.data(), attr.size()))) return r;
+        c->ss.have_frame = frame ? 1 : 0;
+    }
+    {
+        std::vector<float4> mats(sd->n_models);
+        for (uint32_t m = 0; m < sd->n_models; ++m)
+            mats[m] = make_float4(sd->materials[m].diffuse_color[0], sd->materials[m].diffuse_color[1],
+                                  sd->materials[m].diffuse_color[2], sd->materials[m].roughness);
+        if ((r = dev_upload(c, &c->d_materials, mats.data(), mats.size()))) return r;
+    }
+    c->n_lights = (int)sd->n_lights;
+    {
+        std::vector<DevLight> lights(sd->n_lights);
+        c->env.resize(sd->n_lights);
+        for (uint32_t l = 0; l < sd->n_lights; ++l) {
+            const rt_light& s = sd->lights[l];
+            DevLight& d = lights[l];
+            memset(&d, 0, sizeof d);
+            d.type = s.type;
+            d.px = s.pos[0]; d.py = s.pos[1]; d.pz = s.pos[2];
+            d.ix = s.intensity[0]; d.iy = s.intensity[1]; d.iz = s.intensity[2];
+            if (s.type == RT_LIGHT_ENV) {
+                if ((r = build_env(c, s, d, c->env[l]))) return r;
+            } else if (s.type != RT_LIGHT_POINT) {
+                c->err = "unsupported light type (point = 0 and env = 3 are implemented)";
+                return RT_ERR_ARG;
+            }
+        }
+        if ((r = dev_upload(c, &c->d_lights, lights.data(), lights.size()))) return r;
+    }
+    c->ss.tri_attr = c->d_tri_attr;
+    c->ss.materials = c->d_materials;
+    c->ss.lights = c->d_lights;
+    c->ss.n_lights = c->n_lights;
+
+    // ---- film tiles of this rank, slots in 8x8 pixel blocks inside each tile
+    const int W = pr->width, H = pr->height, ts = c->tile;
+    c->tiles_x = (W + ts - 1) / ts;
+    c->tiles_y = (H + ts - 1) / ts;
+    const uint32_t n_tiles = (uint32_t)c->tiles_x * (uint32_t)c->tiles_y;
+    c->n_local_tiles = n_tiles > (uint32_t)rank ? (n_tiles - rank + world - 1) / world : 0;
+    c->n_slots = c->n_local_tiles * ts * ts;
+    c->h_slot_pixel.assign(c->n_slots, 0xFFFFFFFFu);
+    std::vector<uint32_t> q0;
+    q0.reserve(c->n_slots);
+    const int bpr = ts / 8;
+    for (uint32_t k = 0; k < c->n_local_tiles; ++k) {
+        uint32_t t = rank + k * world;
+        int tx = t % c->tiles_x, ty = t / c->tiles_x;
+        for (int i = 0; i < ts * ts; ++i) {
+            int blk = i >> 6, li = i & 63;
+            int x = tx * ts + (blk % bpr) * 8 + (li & 7);
+            int y = ty * ts + (blk / bpr) * 8 + (li >> 3);
+            uint32_t s = k * ts * ts + i;
+            if (x < W && y < H) {
+                c->h_slot_pixel[s] = (uint32_t)y * W + x;
+                q0.push_back(s);
+            }
+        }
+    }
+    c->n_valid = (uint32_t)q0.size();
+    const size_t n = c->n_slots;
+    if ((r = dev_upload(c, &c->d_slot_pixel, c->h_slot_pixel.data(), n))) return r;
+    if ((r = dev_upload(c, &c->d_q0, q0.data(), q0.size()))) return r;
+    if ((r = dev_alloc(c, &c->d_q[0], n))) return r;
+    if ((r = dev_alloc(c, &c->d_q[1], n))) return r;
+    if ((r = dev_alloc(c, &c->pb.rays, 6 * n))) return r;
+    if ((r = dev_alloc(c, &c->pb.hit_t, n))) return r;
+    if ((r = dev_alloc(c, &c->pb.hit_id0, n))) return r;
+    if ((r = dev_alloc(c, &c->pb.hit_id1, n))) return r;
+    if ((r = dev_alloc(c, &c->pb.hit_u, n))) return r;
+    if ((r = dev_alloc(c, &c->pb.hit_v, n))) return r;
+    if ((r = dev_alloc(c, &c->pb.beta, 3 * n))) return r;
+    if ((r = dev_alloc(c, &c->pb.L, 3 * n))) return r;
+    if ((r = dev_alloc(c, &c->pb.vpos, 3 * n))) return r;
+    if ((r = dev_alloc(c, &c->pb.status, n))) return r;
+    if ((r = dev_alloc(c, &c->pb.film, n))) return r;
+    HIP_TRY(c, hipMemset(c->pb.film, 0, (n ? n : 1) * sizeof(float4)));
+    HIP_TRY(c, hipMemset(c->pb.rays, 0, (n ? n : 1) * 6 * sizeof(float)));
+    c->pb.slot_pixel = c->d_slot_pixel;
+    c->pb.n = (uint32_t)n;
+
+    const int D = pr->max_depth, L = c->n_lights;
+    c->n_counts = (uint32_t)(D + 1 + D * L);
+    std::vector<uint32_t> init(c->n_counts, 0u);
+    init[0] = c->n_valid;
+    if ((r = dev_upload(c, &c->d_counts_init, init.data(), init.size()))) return r;
+    if ((r = dev_alloc(c, &c->d_counts, c->n_counts))) return r;
+    c->h_sq.resize(L);
+    for (int l = 0; l < L; ++l) {
+        ShadowQueue& q = c->h_sq[l];
+        q.cap = (uint32_t)n;
+        if ((r = dev_alloc(c, &q.slot, n))) return r;
+        if ((r = dev_alloc(c, &q.dir, 3 * n))) return r;
+        if ((r = dev_alloc(c, &q.contrib, 6 * n))) return r;
+    }
+    if ((r = dev_upload(c, &c->d_sq, c->h_sq.data(), c->h_sq.size()))) return r;
+    if ((r = dev_alloc(c, &c->d_raystats, 2))) return r;
+    HIP_TRY(c, hipMemset(c->d_raystats, 0, 2 * sizeof(unsigned long long)));
+    HIP_TRY(c, hipDeviceSynchronize());
+    return RT_OK;
+}
+
+int rt_create(const rt_scene_desc* scene, const rt_params* params, rt_ctx** out) {
+    if (!scene || !params || !out) {
+        g_create_error = "rt_create: null argument";
+        return RT_ERR_ARG;
+    }
+    *out = nullptr;
+    rt_ctx* c = new rt_ctx();
+    int r = create_impl(c, scene, params);
+    if (r != RT_OK) {
+        g_create_error = c->err;
+        rt_destroy(c);
+        return r;
+    }
+    *out = c;
+    return RT_OK;
+}
+
+int rt_set_camera(rt_ctx* c, const float pos[3], const float right[3], const float up[3], const float forward[3]) {
+    if (!c || !pos || !right || !up || !forward) return RT_ERR_ARG;
+    CameraK k;
+    for (int i = 0; i < 3; ++i) { k.pos[i] = pos[i]; k.right[i] = right[i]; k.up[i] = up[i]; k.forward[i] = forward[i]; }
+    k.W = c->params.width;
+    k.H = c->params.height;
+    // a moved camera restarts accumulation (src/cpu/Integrator.cpp:27-30)
+    if (!c->have_camera || memcmp(&k, &c->cam, sizeof k) != 0) c->frames = 0;
+    c->cam = k;
+    c->have_camera = true;
+    return RT_OK;
+}
+
+int rt_reset_accumulation(rt_ctx* c) {
+    if (!c) return RT_ERR_ARG;
+    c->frames = 0;
+    return RT_OK;
+}
+
+int rt_render(rt_ctx* c, uint32_t n_passes) {
+    if (!c) return RT_ERR_ARG;
+    if (!c->have_camera) {
+        c->err = "rt_render: no camera set";
+        return RT_ERR_STATE;
+    }
+    if (c->frames + n_passes > 0xFFFFull) {
+        c->err = "rt_render: more than 65535 accumulated passes";
+        return RT_ERR_LIMIT;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->n_slots == 0) { c->frames += n_passes; return RT_OK; }
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    for (uint32_t p = 0; p < n_passes; ++p) {
+        int r = run_pass(c);
+        if (r) return r;
+    }
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(&c->last_render_ms, c->ev0, c->ev1));
+    return RT_OK;
+}
+
+int rt_read_film(rt_ctx* c, float* rgba_out) {
+    if (!c || !rgba_out) return RT_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = c->n_slots;
+    std::vector<float> slab(n * 4);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n) HIP_TRY(c, hipMemcpy(slab.data(), c->pb.film, n * sizeof(float4), hipMemcpyDeviceToHost));
+    memset(rgba_out, 0, (size_t)c->params.width * c->params.height * 4 * sizeof(float));
+    for (size_t s = 0; s < n; ++s) {
+        uint32_t pix = c->h_slot_pixel[s];
+        if (pix != 0xFFFFFFFFu) memcpy(rgba_out + (size_t)pix * 4, &slab[s * 4], 4 * sizeof(float));
+    }
+    return RT_OK;
+}
+
+int rt_film_slab(rt_ctx* c, const float** device_ptr, uint32_t* n_tiles, uint64_t* n_floats) {
+    if (!c) return RT_ERR_ARG;
+    if (device_ptr) *device_ptr = reinterpret_cast<const float*>(c->pb.film);
+    if (n_tiles) *n_tiles = c->n_local_tiles;
+    if (n_floats) *n_floats = (uint64_t)c->n_slots * 4;
+    return RT_OK;
+}
+
+int rt_copy_film_slab(rt_ctx* c, void* device_dst, uint64_t n_floats) {
+    if (!c || !device_dst) return RT_ERR_ARG;
+    if (n_floats != (uint64_t)c->n_slots * 4) {
+        c->err = "rt_copy_film_slab: size does not match rt_film_slab";
+        return RT_ERR_ARG;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_floats) HIP_TRY(c, hipMemcpyAsync(device_dst, c->pb.film, n_floats * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int rt_unpack_slabs(int32_t W, int32_t H, int32_t tile, int32_t world, const float* slabs, uint64_t per_rank, float* rgba_out) {
+    if (!slabs || !rgba_out || W <= 0 || H <= 0 || world <= 0) return RT_ERR_ARG;
+    if (tile <= 0) tile = 64;
+    if (tile % 8) return RT_ERR_ARG;
+    const int tiles_x = (W + tile - 1) / tile, tiles_y = (H + tile - 1) / tile;
+    const uint32_t n_tiles = (uint32_t)tiles_x * tiles_y;
+    const int bpr = tile / 8;
+    memset(rgba_out, 0, (size_t)W * H * 4 * sizeof(float));
+    for (int rank = 0; rank < world; ++rank) {
+        const float* slab = slabs + (size_t)rank * per_rank;
+        uint32_t k = 0;
+        for (uint32_t t = rank; t < n_tiles; t += world, ++k) {
+            if (((uint64_t)k + 1) * tile * tile * 4 > per_rank) return RT_ERR_ARG;
+            int tx = t % tiles_x, ty = t / tiles_x;
+            for (int i = 0; i < tile * tile; ++i) {
+                int blk = i >> 6, li = i & 63;
+                int x = tx * tile + (blk % bpr) * 8 + (li & 7);
+                int y = ty * tile + (blk / bpr) * 8 + (li >> 3);
+                if (x < W && y < H)
+                    memcpy(rgba_out + ((size_t)y * W + x) * 4, slab + ((size_t)k * tile * tile + i) * 4, 4 * sizeof(float));
+            }
+        }
+    }
+    return RT_OK;
+}
+
+int rt_trace_closest_dev(rt_ctx* c, uint32_t n, const float* d_rays, float* d_t, int32_t* d_id0, int32_t* d_id1, float* d_u,
+                         float* d_v, uint32_t repeat) {
+    if (!c || !d_rays || !d_t || !d_id0 || !d_id1 || !d_u || !d_v) return RT_ERR_ARG;
+    if (n == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return launch_closest(c, n, d_rays, d_t, d_id0, d_id1, d_u, d_v, repeat);
+}
+
+int rt_trace_occluded_dev(rt_ctx* c, uint32_t n, const float* d_rays, int32_t* d_status, uint32_t repeat) {
+    if (!c || !d_rays || !d_status) return RT_ERR_ARG;
+    if (n == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return launch_occluded(c, n, d_rays, d_status, repeat);
+}
+
+int rt_trace_closest(rt_ctx* c, uint32_t n, const float* rays, float* dist, int32_t* id0, int32_t* id1, float* u, float* v) {
+    if (!c || !rays || !dist || !id0 || !id1 || !u || !v) return RT_ERR_ARG;
+    if (n == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r = ensure_trace_staging(c, n);
+    if (r) return r;
+    HIP_TRY(c, hipMemcpy(c->d_tr_rays, rays, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    float* o = c->d_tr_out;
+    r = launch_closest(c, n, c->d_tr_rays, o, reinterpret_cast<int32_t*>(o + n), reinterpret_cast<int32_t*>(o + 2 * (size_t)n),
+                       o + 3 * (size_t)n, o + 4 * (size_t)n, 1);
+    if (r) return r;
+    HIP_TRY(c, hipMemcpy(dist, o, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(id0, o + n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(id1, o + 2 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(u, o + 3 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(v, o + 4 * (size_t)n, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_trace_occluded(rt_ctx* c, uint32_t n, const float* rays, int32_t* status) {
+    if (!c || !rays || !status) return RT_ERR_ARG;
+    if (n == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r = ensure_trace_staging(c, n);
+    if (r) return r;
+    HIP_TRY(c, hipMemcpy(c->d_tr_rays, rays, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    r = launch_occluded(c, n, c->d_tr_rays, reinterpret_cast<int32_t*>(c->d_tr_out), 1);
+    if (r) return r;
+    HIP_TRY(c, hipMemcpy(status, c->d_tr_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_get_bvh(rt_ctx* c, uint32_t* n_nodes, float* boxes, int32_t* left, int32_t* right, int32_t* tri, int32_t* model,
+               int32_t* leaf) {
+    if (!c || !n_nodes) return RT_ERR_ARG;
+    const auto& ref = c->bvh.ref;
+    *n_nodes = (uint32_t)ref.size();
+    if (!boxes) return RT_OK;
+    if (!left || !right || !tri || !model || !leaf) return RT_ERR_ARG;
+    for (size_t i = 0; i < ref.size(); ++i) {
+        for (int k = 0; k < 3; ++k) { boxes[6 * i + k] = ref[i].bmin[k]; boxes[6 * i + 3 + k] = ref[i].bmax[k]; }
+        left[i] = ref[i].left; right[i] = ref[i].right; tri[i] = ref[i].tri; model[i] = ref[i].model; leaf[i] = ref[i].leaf;
+    }
+    return RT_OK;
+}
+
+int rt_lbvh_host(const float* pos, uint32_t pos_stride, const uint32_t* indices, uint32_t n_indices, const int32_t* tri_model,
+                 int32_t* max_depth, float* boxes, int32_t* left, int32_t* right, int32_t* tri, int32_t* model, int32_t* leaf) {
+    if (!pos || !indices || !tri_model || n_indices < 3 || n_indices % 3 || !boxes || !left || !right || !tri || !model || !leaf)
+        return RT_ERR_ARG;
+    LbvhResult res;
+    build_lbvh(pos, pos_stride ? pos_stride : 12, indices, n_indices, tri_model, res);
+    if (max_depth) *max_depth = res.max_depth;
+    for (size_t i = 0; i < res.ref.size(); ++i) {
+        for (int k = 0; k < 3; ++k) { boxes[6 * i + k] = res.ref[i].bmin[k]; boxes[6 * i + 3 + k] = res.ref[i].bmax[k]; }
+        left[i] = res.ref[i].left; right[i] = res.ref[i].right; tri[i] = res.ref[i].tri; model[i] = res.ref[i].model;
+        leaf[i] = res.ref[i].leaf;
+    }
+    return RT_OK;
+}
+
+uint32_t rt_morton3d(float x, float y, float z) { return morton3d(x, y, z); }
+
+int rt_get_stats(rt_ctx* c, rt_stats* out) {
+    if (!c || !out) return RT_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    unsigned long long rs[2] = {0, 0};
+    HIP_TRY(c, hipMemcpy(rs, c->d_raystats, sizeof rs, hipMemcpyDeviceToHost));
+    memset(out, 0, sizeof *out);
+    out->closest_rays = rs[0];
+    out->shadow_rays = rs[1];
+    out->passes = c->frames;
+    out->n_nodes = (uint32_t)c->bvh.ref.size();
+    out->n_triangles = (uint32_t)c->bvh.tris.size();
+    out->bvh_max_depth = c->bvh.max_depth;
+    out->n_local_pixels = c->n_valid;
+    out->last_trace_ms = c->last_trace_ms;
+    out->last_render_ms = c->last_render_ms;
+    out->bvh_build_ms = c->bvh_build_ms;
+    return RT_OK;
+}
+
+int rt_synchronize(rt_ctx* c) {
+    if (!c) return RT_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,527 @@
+// Wavefront path-tracing stages for gfx950 (everything of
+// PathTracer::computeTile, src/cpu/PathTracer.cpp:17-164, that is not BVH
+// traversal): camera-ray generation, per-bounce shading with light sampling
+// and BSDF sampling, shadow-ray resolution, film accumulation.  Path state
+// is SoA, one slot per film pixel of this rank; stages talk through queues
+// of slot ids compacted with wave ballots (one atomic per wave).
+#pragma once
+#include "trace.h"
+
+namespace rt {
+
+#define RT_LIGHT_POINT_K 0
+#define RT_LIGHT_ENV_K 3
+
+struct DevLight {
+    int32_t type;
+    float px, py, pz;      // point position
+    float ix, iy, iz;      // point intensity / env scale
+    int32_t W, H;          // env image size
+    const float4* img;     // env texels, row-major
+    // Distribution2D built as EnvLight's ctor does (src/lights/EnvLight.cpp:16-25):
+    // W conditional rows of H entries each, marginal over the W rows.
+    const float* cond_func;  // [W][H]
+    const float* cond_cdf;   // [W][H+1]
+    const float* cond_int;   // [W] (also the marginal's func)
+    const float* marg_cdf;   // [W+1]
+    float marg_int;
+};
+
+struct PathBuffers {
+    float* rays;        // 6 planes: ox oy oz dx dy dz
+    float* hit_t;
+    int32_t* hit_id0;
+    int32_t* hit_id1;
+    float* hit_u;
+    float* hit_v;
+    float* beta;        // 3 planes (the reference's `threshold`)
+    float* L;           // 3 planes (the reference's `pixelColor`)
+    float* vpos;        // 3 planes: position of the vertex being shaded
+    uint32_t* status;   // 1 = the primary ray hit (film takes the running mean)
+    const uint32_t* slot_pixel;  // y*W+x, or 0xFFFFFFFF for a slot outside the film
+    float4* film;
+    uint32_t n;         // slots
+};
+
+struct ShadeScene {
+    const float* tri_attr;      // 36 floats per triangle: 3 x (normal3 uv2 tangent3 binormal3), 3 pad
+    const float4* materials;    // per model: rgb, roughness
+    const DevLight* lights;
+    int32_t n_lights;
+    int32_t have_frame;
+};
+
+struct CameraK {
+    float pos[3], right[3], up[3], forward[3];
+    int32_t W, H;
+};
+
+constexpr float kPi = 3.14159265358979323846f;  // (float)M_PI
+constexpr float kInvPi = 1.0f / kPi;            // src/bsdf/Samples.hpp:10-13
+constexpr float kInv2Pi = 1.0f / (2.f * kPi);
+constexpr float kPiOver2 = kPi / 2.f;
+constexpr float kPiOver4 = kPiOver2 / 2.f;
+
+// Appends the lanes with pred set to a queue: one atomic per wave.  Must be
+// reached by every lane of the wave.
+RT_DEV uint32_t wave_append(bool pred, uint32_t* counter) {
+    unsigned long long m = __ballot(pred);
+    uint32_t lane = __lane_id();
+    uint32_t prefix = __popcll(m & ((1ull << lane) - 1ull));
+    uint32_t base = 0;
+    if (m) {
+        int leader = __ffsll((unsigned long long)m) - 1;
+        if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+        base = __shfl(base, leader);
+    }
+    return base + prefix;
+}
+
+// --------------------------------------------------------------- sampling
+// src/bsdf/Samples.hpp:15-28
+RT_DEV f2 concentric_sample_disk(f2 u) {
+    f2 uo; uo.x = 2.f * u.x - 1.f; uo.y = 2.f * u.y - 1.f;
+    f2 r0; r0.x = 0.f; r0.y = 0.f;
+    if (uo.x == 0 && uo.y == 0) return r0;
+    float theta, r;
+    if (fabsf(uo.x) > fabsf(uo.y)) {
+        r = uo.x;
+        theta = kPiOver4 * (uo.y / uo.x);
+    } else {
+        r = uo.y;
+        theta = kPiOver2 - kPiOver4 * (uo.x / uo.y);
+    }
+    f2 o; o.x = r * cosf(theta); o.y = r * sinf(theta);
+    return o;
+}
+// src/bsdf/Samples.hpp:30-34: the cosine-weighted axis is written to y
+RT_DEV f3 cosine_sample_hemisphere(f2 u) {
+    f2 d = concentric_sample_disk(u);
+    float z = sqrtf(gmax(0.f, 1.f - d.x * d.x - d.y * d.y));
+    return mk3(d.x, z, d.y);
+}
+// src/bsdf/Samples.hpp:36-43
+RT_DEV float spherical_theta(f3 v) { return acosf(clampf(v.y, -1.f, 1.f)); }
+RT_DEV float spherical_phi(f3 v) {
+    float p = atan2f(-v.z, -v.x);
+    return (p < 0.f) ? (p + 2.f * kPi) : p;
+}
+
+// ------------------------------------------------------------------- BSDF
+// src/bsdf/BxDF.hpp:38-64
+RT_DEV float abs_cos_theta(f3 w) { return fabsf(w.z); }
+RT_DEV float sin2_theta(f3 w) { return gmax(0.f, 1.f - w.z * w.z); }
+RT_DEV float sin_theta(f3 w) { return sqrtf(sin2_theta(w)); }
+RT_DEV float cos_phi(f3 w) { float s = sin_theta(w); return (s == 0) ? 1.f : clampf(w.x / s, -1.f, 1.f); }
+RT_DEV float sin_phi(f3 w) { float s = sin_theta(w); return (s == 0) ? 0.f : clampf(w.y / s, -1.f, 1.f); }
+
+// Oren–Nayar lobe, src/bsdf/Diffuse.cpp:7-32
+struct DiffuseK {
+    f3 color;
+    float A, B;
+};
+RT_DEV DiffuseK make_diffuse(f3 color, float sigma) {
+    DiffuseK d;
+    d.color = color;
+    float sigma2 = sigma * sigma;
+    d.A = 1.f - (sigma2 / (2.f * (sigma2 + 0.33f)));
+    d.B = 0.45f * sigma2 / (sigma2 + 0.09f);
+    return d;
+}
+RT_DEV f3 diffuse_f(const DiffuseK& k, f3 out, f3 in) {
+    float sinThetaI = sin_theta(in), sinThetaO = sin_theta(out);
+    float maxCos = 0;
+    if ((double)sinThetaI > 1e-4 && (double)sinThetaO > 1e-4) {
+        float sinPhiI = sin_phi(in), cosPhiI = cos_phi(in);
+        float sinPhiO = sin_phi(out), cosPhiO = cos_phi(out);
+        float dCos = cosPhiI * cosPhiO + sinPhiI * sinPhiO;
+        maxCos = gmax(0.f, dCos);
+    }
+    float sinAlpha, tanBeta;
+    if (abs_cos_theta(in) > abs_cos_theta(out)) {
+        sinAlpha = sinThetaO;
+        tanBeta = sinThetaI / abs_cos_theta(in);
+    } else {
+        sinAlpha = sinThetaI;
+        tanBeta = sinThetaO / abs_cos_theta(out);
+    }
+    return k.color * kInvPi * (k.A + k.B * maxCos * sinAlpha * tanBeta);
+}
+// src/bsdf/BxDF.cpp:15-17
+RT_DEV float diffuse_pdf(f3 out, f3 in) { return (out.z * in.z > 0) ? abs_cos_theta(in) * kInvPi : 0.f; }
+// src/bsdf/BxDF.cpp:8-13
+RT_DEV f3 diffuse_sampled(const DiffuseK& k, f3 out, f2 u, f3& in, float& pdf) {
+    in = cosine_sample_hemisphere(u);
+    if (out.z < 0) in.z *= -1;
+    pdf = diffuse_pdf(out, in);
+    return diffuse_f(k, out, in);
+}
+
+// BSDF with its single Diffuse lobe, src/bsdf/BSDF.cpp:7-104
+struct BsdfK {
+    f3 t, b, n;
+    DiffuseK lobe;
+};
+RT_DEV f3 world2local(const BsdfK& s, f3 v) { return mk3(dot3(s.t, v), dot3(s.b, v), dot3(s.n, v)); }
+RT_DEV f3 local2world(const BsdfK& s, f3 v) {
+    return mk3(s.t.x * v.x + s.b.x * v.y + s.n.x * v.z, s.t.y * v.x + s.b.y * v.y + s.n.y * v.z,
+               s.t.z * v.x + s.b.z * v.y + s.n.z * v.z);
+}
+RT_DEV f3 bsdf_f(const BsdfK& s, f3 outW, f3 inW) {
+    f3 in = world2local(s, inW), out = world2local(s, outW);
+    bool reflect = dot3(inW, s.n) * dot3(outW, s.n) > 0;
+    f3 r = mk3(0.f, 0.f, 0.f);
+    if (reflect) r = r + diffuse_f(s.lobe, out, in);
+    return r;
+}
+RT_DEV float bsdf_pdf(const BsdfK& s, f3 outW, f3 inW) {
+    f3 out = world2local(s, outW), in = world2local(s, inW);
+    float p = 0.f;
+    p += diffuse_pdf(out, in);
+    p /= 1.0f;
+    return p;
+}
+RT_DEV f3 bsdf_sample(const BsdfK& s, f3 outW, f2 u, f3& inW, float& pdf) {
+    pdf = 0.f;
+    int comp = min((int)floorf(u.x * 1), 0);
+    f2 uR; uR.x = u.x * 1 - comp; uR.y = u.y;
+    f3 wi, wo = world2local(s, outW);
+    f3 fr = diffuse_sampled(s.lobe, wo, uR, wi, pdf);
+    if (pdf == 0) return mk3(0.f, 0.f, 0.f);
+    inW = local2world(s, wi);
+    return fr;
+}
+
+// ---------------------------------------------------------- distributions
+// src/scene/Common.hpp:13-25 with the predicate cdf[i] <= u
+RT_DEV int find_interval_cdf(const float* cdf, int size, float u) {
+    int first = 0, len = size;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) {
+            first = middle + 1;
+            len -= half + 1;
+        } else
+            len = half;
+    }
+    return (int)clampf((float)(first - 1), 0.f, (float)(size - 2));
+}
+// src/samplers/Distributions.cpp:26-35
+RT_DEV float dist1d_sample(const float* cdf, const float* func, float funcInt, int n, float u, float& pdf, int& off) {
+    int offset = find_interval_cdf(cdf, n + 1, u);
+    off = offset;
+    float c0 = cdf[offset], c1 = cdf[offset + 1];
+    float du = u - c0;
+    if ((c1 - c0) > 0) du /= (c1 - c0);
+    pdf = func[offset] / funcInt;
+    return ((float)offset + du) / (float)n;
+}
+
+// Bilinear RGBA32F fetch (repeat wrap, texel centres at +0.5); the
+// reference's filterLinear lives in its absent Mango dependency.
+RT_DEV f3 filter_linear(const float4* img, int W, int H, f2 uv) {
+    float x = uv.x * (float)W - 0.5f, y = uv.y * (float)H - 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float fx = x - fx0, fy = y - fy0;
+    int x0 = (int)fx0, y0 = (int)fy0;
+    int xa = x0 % W; if (xa < 0) xa += W;
+    int xb = (x0 + 1) % W; if (xb < 0) xb += W;
+    int ya = y0 % H; if (ya < 0) ya += H;
+    int yb = (y0 + 1) % H; if (yb < 0) yb += H;
+    float4 p00 = img[(size_t)ya * W + xa], p10 = img[(size_t)ya * W + xb];
+    float4 p01 = img[(size_t)yb * W + xa], p11 = img[(size_t)yb * W + xb];
+    f3 top = mk3(p00.x, p00.y, p00.z) * (1.0f - fx) + mk3(p10.x, p10.y, p10.z) * fx;
+    f3 bot = mk3(p01.x, p01.y, p01.z) * (1.0f - fx) + mk3(p11.x, p11.y, p11.z) * fx;
+    return top * (1.0f - fy) + bot * fy;
+}
+
+// ----------------------------------------------------------------- lights
+// src/lights/PointLight.cpp:14-18, src/lights/EnvLight.cpp:28-43
+RT_DEV f3 light_sample(const DevLight& l, f3 p, f2 u, f3& in, float& pdf) {
+    if (l.type == RT_LIGHT_POINT_K) {
+        f3 lp = mk3(l.px, l.py, l.pz);
+        in = normalize3(lp - p);
+        pdf = 1.f;
+        f3 d = lp - p;
+        return mk3(l.ix, l.iy, l.iz) / dot3(d, d);
+    }
+    // Distribution2D::sampleContinuous, src/samplers/Distributions.cpp:60-68
+    float pdf0, pdf1;
+    int v, dummy;
+    float d1 = dist1d_sample(l.marg_cdf, l.cond_int, l.marg_int, l.W, u.y, pdf1, v);
+    float d0 = dist1d_sample(l.cond_cdf + (size_t)v * (l.H + 1), l.cond_func + (size_t)v * l.H, l.cond_int[v], l.H, u.x, pdf0, dummy);
+    float mapPdf = pdf0 * pdf1;
+    pdf = 0.0f;
+    in = mk3(0.f, 0.f, 0.f);
+    if (mapPdf == 0) return mk3(0.f, 0.f, 0.f);
+    float theta = d0 * kPi, phi = d1 * 2.f * kPi;
+    float cosT = cosf(theta), sinT = sinf(theta);
+    float sinP = sinf(phi), cosP = cosf(phi);
+    in = mk3(sinT * cosP, sinT * sinP, cosT);
+    pdf = mapPdf / (2 * kPi * kPi * sinT);
+    if (!isfinite(pdf)) pdf = 0.0f;
+    f2 uv; uv.x = d0; uv.y = d1;
+    return filter_linear(l.img, l.W, l.H, uv) * mk3(l.ix, l.iy, l.iz);
+}
+// src/lights/PointLight.cpp:20-22, src/lights/EnvLight.cpp:45-52 with
+// Distribution2D::pdf, src/samplers/Distributions.cpp:70-76
+RT_DEV float light_pdf(const DevLight& l, f3 inW) {
+    if (l.type == RT_LIGHT_POINT_K) return 1.0f;
+    float theta = spherical_theta(inW), phi = spherical_phi(inW);
+    float sinT = sinf(theta);
+    if (sinT == 0) return 0.f;
+    float p0 = phi * kInv2Pi, p1 = theta * kInvPi;
+    int iu = (int)clampf((float)(int)(p0 * l.H), 0.f, (float)(l.H - 1));
+    int iv = (int)clampf((float)(int)(p1 * l.W), 0.f, (float)(l.W - 1));
+    float dp = l.cond_func[(size_t)iv * l.H + iu] / l.marg_int;
+    return dp / (2 * kPi * kPi * sinT);
+}
+// src/lights/LightSource.hpp:28-30, src/lights/EnvLight.cpp:60-65
+RT_DEV f3 light_le(const DevLight& l, f3 dir) {
+    if (l.type == RT_LIGHT_POINT_K) return mk3(0.f, 0.f, 0.f);
+    f3 w = normalize3(dir);
+    f2 st; st.x = spherical_phi(w) * kInv2Pi; st.y = spherical_theta(w) * kInvPi;
+    return filter_linear(l.img, l.W, l.H, st);
+}
+
+// Random-number slot layout of one path vertex at depth d with L lights.
+RT_DEV uint32_t dim_light(int d, int L, int l, int k) { return (uint32_t)(d * (4 * L + 2) + 4 * l + k); }
+RT_DEV uint32_t dim_bounce(int d, int L, int k) { return (uint32_t)(d * (4 * L + 2) + 4 * L + k); }
+
+// ---------------------------------------------------------------- kernels
+// Camera rays, src/cpu/PathTracer.cpp:43-52; also clears the per-pass state.
+__global__ __launch_bounds__(RT_BLOCK) void k_generate(PathBuffers pb, CameraK cam) {
+    uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (s >= pb.n) return;
+    uint32_t pix = pb.slot_pixel[s];
+    pb.status[s] = 0;
+    size_t n = pb.n;
+    pb.beta[s] = 1.f; pb.beta[n + s] = 1.f; pb.beta[2 * n + s] = 1.f;
+    pb.L[s] = 0.f; pb.L[n + s] = 0.f; pb.L[2 * n + s] = 0.f;
+    if (pix == 0xFFFFFFFFu) return;
+    int x = (int)(pix % (uint32_t)cam.W), y = (int)(pix / (uint32_t)cam.W);
+    float ni = ((float)x / (float)cam.W) - 0.5f;
+    float nj = ((float)y / (float)cam.H) - 0.5f;
+    nj = -nj;
+    nj *= ((float)cam.H / (float)cam.W);
+    f3 right = mk3(cam.right[0], cam.right[1], cam.right[2]);
+    f3 up = mk3(cam.up[0], cam.up[1], cam.up[2]);
+    f3 fwd = mk3(cam.forward[0], cam.forward[1], cam.forward[2]);
+    f3 ip = ni * right + nj * up + fwd;
+    f3 d = normalize3(ip);
+    pb.rays[s] = cam.pos[0]; pb.rays[n + s] = cam.pos[1]; pb.rays[2 * n + s] = cam.pos[2];
+    pb.rays[3 * n + s] = d.x; pb.rays[4 * n + s] = d.y; pb.rays[5 * n + s] = d.z;
+}
+
+// Shadow-ray queue of one light: slot, direction and the two contributions
+// the reference adds, one after the other, once the ray is found unoccluded
+// (src/cpu/PathTracer.cpp:107 or :109, then :123).  Planes of `cap` entries.
+struct ShadowQueue {
+    uint32_t* slot;
+    float* dir;      // 3 planes
+    float* contrib;  // 6 planes: first term rgb, second term rgb
+    uint32_t cap;
+};
+
+// One bounce of src/cpu/PathTracer.cpp:56-65 (d = 0 miss) and :95-144 for
+// every path in the queue: BVH::postIntersect (src/scene/BVH.cpp:172-187),
+// Material::computeBSDF (src/scene/Material.cpp:214-225), per-light sampling
+// with the contributions the reference would add once the shadow ray is
+// found unoccluded, then the BSDF bounce.  sq[l] / sq_counts[l] belong to
+// light l of this bounce.
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene sc, int depth, int max_depth, uint64_t seed_mixed,
+                                                    uint32_t pass, const uint32_t* __restrict__ queue,
+                                                    const uint32_t* __restrict__ d_count, uint32_t* __restrict__ next_queue,
+                                                    uint32_t* __restrict__ next_count, const ShadowQueue* __restrict__ sq,
+                                                    uint32_t* __restrict__ sq_counts) {
+    const uint32_t count = *d_count;
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t gsize = gridDim.x * RT_BLOCK;
+    const uint32_t lane = gtid & 63u;
+    const size_t n = pb.n;
+    const int L = sc.n_lights;
+    // every lane of a wave runs the same number of iterations (ballots inside)
+    for (uint32_t base = gtid - lane; base < count; base += gsize) {
+        uint32_t i = base + lane;
+        bool valid = i < count;
+        uint32_t s = valid ? queue[i] : 0u;
+        bool hit = false;
+        f3 org = mk3(0.f, 0.f, 0.f), dir = mk3(0.f, 0.f, 1.f);
+        int32_t id0 = -1, id1 = -1;
+        if (valid) {
+            org = mk3(pb.rays[s], pb.rays[n + s], pb.rays[2 * n + s]);
+            dir = mk3(pb.rays[3 * n + s], pb.rays[4 * n + s], pb.rays[5 * n + s]);
+            id1 = pb.hit_id1[s];
+            id0 = pb.hit_id0[s];
+            hit = id1 >= 0;
+            if (!hit && depth == 0) {
+                // src/cpu/PathTracer.cpp:61-65: the film takes the summed le, no accumulation
+                f3 Lm = mk3(0.f, 0.f, 0.f);
+                for (int l = 0; l < L; ++l) Lm = Lm + light_le(sc.lights[l], dir);
+                pb.film[s] = make_float4(Lm.x, Lm.y, Lm.z, 1.0f);
+            }
+        }
+        BsdfK bsdf;
+        bsdf.t = mk3(1.f, 0.f, 0.f); bsdf.b = mk3(0.f, 1.f, 0.f); bsdf.n = mk3(0.f, 0.f, 1.f);
+        bsdf.lobe = make_diffuse(mk3(0.f, 0.f, 0.f), 0.f);
+        f3 vpos = mk3(0.f, 0.f, 0.f), vn = mk3(0.f, 0.f, 1.f), out = mk3(0.f, 0.f, 1.f);
+        f3 beta = mk3(1.f, 1.f, 1.f);
+        uint32_t pixel = 0;
+        if (hit) {
+            if (depth == 0) pb.status[s] = 1;
+            pixel = pb.slot_pixel[s];
+            float t = pb.hit_t[s], hu = pb.hit_u[s], hv = pb.hit_v[s];
+            float bc[3] = {1.0f - hu - hv, hu, hv};
+            vpos = org + dir * t;
+            const float* at = sc.tri_attr + (size_t)(id1 / 3) * 36;
+            f3 nrm = mk3(0.f, 0.f, 0.f), tan = mk3(0.f, 0.f, 0.f), bin = mk3(0.f, 0.f, 0.f);
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const float* a = at + v * 11;
+                nrm = nrm + mk3(a[0], a[1], a[2]) * bc[v];
+                tan = tan + mk3(a[5], a[6], a[7]) * bc[v];
+                bin = bin + mk3(a[8], a[9], a[10]) * bc[v];
+            }
+            nrm = normalize3(nrm);
+            if (sc.have_frame) {
+                bin = normalize3(bin);
+                tan = normalize3(tan);
+            } else {
+                // no tangents supplied: orthonormal frame from the normal
+                if (fabsf(nrm.x) > fabsf(nrm.y)) {
+                    float il = 1.0f / sqrtf(nrm.x * nrm.x + nrm.z * nrm.z);
+                    tan = mk3(-nrm.z * il, 0.0f, nrm.x * il);
+                } else {
+                    float il = 1.0f / sqrtf(nrm.y * nrm.y + nrm.z * nrm.z);
+                    tan = mk3(0.0f, nrm.z * il, -nrm.y * il);
+                }
+                bin = cross3(nrm, tan);
+            }
+            vn = nrm;
+            float4 m = sc.materials[id0];
+            f3 col = mk3(255.0f, 255.0f, 255.0f) / 255.0f;
+            col = col * mk3(m.x, m.y, m.z);
+            bsdf.t = tan; bsdf.b = bin; bsdf.n = nrm;
+            bsdf.lobe = make_diffuse(col, m.w);
+            out = -dir;
+            pb.vpos[s] = vpos.x; pb.vpos[n + s] = vpos.y; pb.vpos[2 * n + s] = vpos.z;
+            beta = mk3(pb.beta[s], pb.beta[n + s], pb.beta[2 * n + s]);
+        }
+
+        // ---- light loop, src/cpu/PathTracer.cpp:96-125
+        for (int l = 0; l < L; ++l) {
+            bool emit = false;
+            f3 in = mk3(0.f, 0.f, 0.f), C = mk3(0.f, 0.f, 0.f), C2 = mk3(0.f, 0.f, 0.f);
+            if (hit) {
+                const DevLight& light = sc.lights[l];
+                float lightPdf;
+                f2 u;
+                u.x = rng_u01(seed_mixed, pixel, pass, dim_light(depth, L, l, 0));
+                u.y = rng_u01(seed_mixed, pixel, pass, dim_light(depth, L, l, 1));
+                f3 li = light_sample(light, vpos, u, in, lightPdf);
+                if (lightPdf != 0.0f) {
+                    emit = true;
+                    f3 bsdfColor = bsdf_f(bsdf, out, in);
+                    float bsdfPdf = bsdf_pdf(bsdf, out, in);
+                    if (light.type == RT_LIGHT_POINT_K) {
+                        C = beta * bsdfColor * li / lightPdf;
+                    } else {
+                        C = beta * bsdfColor * li * power_heuristic(lightPdf, bsdfPdf) / lightPdf;
+                        f3 inBSDF;
+                        f2 u2;
+                        u2.x = rng_u01(seed_mixed, pixel, pass, dim_light(depth, L, l, 2));
+                        u2.y = rng_u01(seed_mixed, pixel, pass, dim_light(depth, L, l, 3));
+                        f3 f = bsdf_sample(bsdf, out, u2, inBSDF, bsdfPdf);
+                        if (bsdfPdf != 0.0f) {
+                            f = f * fabsf(dot3(in, vn));
+                            float lp = light_pdf(light, in);
+                            if (lp != 0.0f) {
+                                float weight = power_heuristic(bsdfPdf, lp);
+                                f3 li2 = light_le(light, dir);
+                                if (!is_zero3(li2)) C2 = f * li2 * weight / bsdfPdf;
+                            }
+                        }
+                    }
+                }
+            }
+            uint32_t k = wave_append(emit, sq_counts + l);
+            if (emit) {
+                const ShadowQueue q = sq[l];
+                size_t cap = q.cap;
+                q.slot[k] = s;
+                q.dir[k] = in.x; q.dir[cap + k] = in.y; q.dir[2 * cap + k] = in.z;
+                q.contrib[k] = C.x; q.contrib[cap + k] = C.y; q.contrib[2 * cap + k] = C.z;
+                q.contrib[3 * cap + k] = C2.x; q.contrib[4 * cap + k] = C2.y; q.contrib[5 * cap + k] = C2.z;
+            }
+        }
+
+        // ---- BSDF bounce, src/cpu/PathTracer.cpp:127-144.  The closest-hit
+        // ray of the last iteration feeds nothing and is not generated.
+        bool alive = false;
+        if (hit && depth + 1 < max_depth) {
+            f3 nextDir = mk3(0.f, 0.f, 0.f);
+            float nextPDF = 0.0f;
+            f2 u3;
+            u3.x = rng_u01(seed_mixed, pixel, pass, dim_bounce(depth, L, 0));
+            u3.y = rng_u01(seed_mixed, pixel, pass, dim_bounce(depth, L, 1));
+            f3 bsdfColor = bsdf_sample(bsdf, out, u3, nextDir, nextPDF);
+            if (!(is_zero3(bsdfColor) || nextPDF == 0.0f)) {
+                alive = true;
+                beta = beta * (bsdfColor * fabsf(dot3(nextDir, vn)) / nextPDF);
+                pb.beta[s] = beta.x; pb.beta[n + s] = beta.y; pb.beta[2 * n + s] = beta.z;
+                pb.rays[s] = vpos.x; pb.rays[n + s] = vpos.y; pb.rays[2 * n + s] = vpos.z;
+                pb.rays[3 * n + s] = nextDir.x; pb.rays[4 * n + s] = nextDir.y; pb.rays[5 * n + s] = nextDir.z;
+            }
+        }
+        uint32_t k = wave_append(alive, next_count);
+        if (alive) next_queue[k] = s;
+    }
+}
+
+// Resolves one light's shadow queue: BVH::occluded from the shaded vertex
+// (src/cpu/PathTracer.cpp:101-102), then the adds of :107/:109 and :123.
+// Each path has at most one entry per light, so the adds do not race, and
+// the per-light launches run in light order like the reference's loop.
+__global__ __launch_bounds__(RT_BLOCK) void k_shadow(TraceScene ts, PathBuffers pb, ShadowQueue q, const uint32_t* __restrict__ d_count,
+                                                     unsigned long long* __restrict__ ray_counter) {
+    __shared__ int32_t s_stack[RT_STACK_LDS * RT_BLOCK];
+    const uint32_t count = *d_count;
+    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
+    const uint32_t gsize = gridDim.x * RT_BLOCK;
+    const size_t n = pb.n, cap = q.cap;
+    if (gtid == 0) atomicAdd(ray_counter, (unsigned long long)count);
+    for (uint32_t i = gtid; i < count; i += gsize) {
+        uint32_t s = q.slot[i];
+        f3 org = mk3(pb.vpos[s], pb.vpos[n + s], pb.vpos[2 * n + s]);
+        f3 dir = mk3(q.dir[i], q.dir[cap + i], q.dir[2 * cap + i]);
+        HitRec h = trace_ray<true>(ts, org, dir, s_stack, gtid);
+        if (h.id1 < 0) {
+            f3 Lp = mk3(pb.L[s], pb.L[n + s], pb.L[2 * n + s]);
+            Lp = Lp + mk3(q.contrib[i], q.contrib[cap + i], q.contrib[2 * cap + i]);
+            f3 C2 = mk3(q.contrib[3 * cap + i], q.contrib[4 * cap + i], q.contrib[5 * cap + i]);
+            if (!is_zero3(C2)) Lp = Lp + C2;
+            pb.L[s] = Lp.x; pb.L[n + s] = Lp.y; pb.L[2 * n + s] = Lp.z;
+        }
+    }
+}
+
+// Film update, src/cpu/PathTracer.cpp:148-157: running mean over passes for
+// pixels whose primary ray hit.  In place: the reference's ping-pong pair
+// only ever reads the previous value of the same pixel.
+__global__ __launch_bounds__(RT_BLOCK) void k_film(PathBuffers pb, float frames) {
+    uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (s >= pb.n || pb.status[s] != 1) return;
+    size_t n = pb.n;
+    f3 c = mk3(pb.L[s], pb.L[n + s], pb.L[2 * n + s]);
+    if (frames != 0.0f) {
+        float4 p = pb.film[s];
+        f3 prev = mk3(p.x, p.y, p.z);
+        prev = prev * frames;
+        prev = prev + c;
+        prev = prev / (frames + 1.f);
+        c = prev;
+    }
+    pb.film[s] = make_float4(c.x, c.y, c.z, 1.0f);
+}
+
+}  // namespace rt
