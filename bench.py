@@ -1,0 +1,194 @@
+"""Headline benchmark: closest-hit BVH traversal on the 1080p Sponza-class
+scene, coherent (pinhole camera) + randomised incoherent ray sets, inputs
+resident in HBM (BASELINE.json configs[1]).
+
+One step = one launch of the closest-hit kernel over each of the two ray sets
+(2 x 2,073,600 rays).  With N > 1 every rank traces ray sets of that size on
+its own GPU (scene replicated, no data-path collective): weak scaling.
+A second, untimed-for-`value` leg renders sample passes of the path tracer at
+1920x1080 and reports samples/s beside the headline.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def algorithmic_bytes(n_rays: int, n_inner: int, n_tri: int) -> float:
+    """Bytes the reference's binary-tree algorithm must move for a ray set:
+    24 B ray in + 20 B hit out per ray, 56 B per inner-node visit (two child
+    boxes + two links), 36 B per triangle test (three positions)."""
+    return 44.0 * n_rays + 56.0 * n_inner + 36.0 * n_tri
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--render-passes", type=int, default=4, help="sample passes of the path-tracing leg (0 = skip)")
+    ap.add_argument("--render-depth", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    from raytracer_amd import Context, scenes
+
+    W, H = args.width, args.height
+    scene = scenes.sponza_class()
+    ctx = Context(scene, W, H, max_depth=args.render_depth, seed=0, device=local_rank)
+    n = W * H
+    coherent = scenes.camera_rays_numpy(scene.camera, W, H)
+    incoherent = scenes.incoherent_rays(scene, n, seed=0x5EED + rank)
+    sets = {"coherent": coherent, "incoherent": incoherent}
+    d_rays = {k: torch.from_numpy(v).to(dev) for k, v in sets.items()}
+    out_f = torch.empty((3, n), dtype=torch.float32, device=dev)
+    out_i = torch.empty((2, n), dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step(times=None):
+        for k in ("coherent", "incoherent"):
+            ctx.trace_closest_dev(n, d_rays[k].data_ptr(), out_f[0].data_ptr(), out_i[0].data_ptr(), out_i[1].data_ptr(),
+                                  out_f[1].data_ptr(), out_f[2].data_ptr(), 1)
+            if times is not None:
+                times[k].append(ctx.last_trace_ms())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    kernel_ms = {"coherent": [], "incoherent": []}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(kernel_ms)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    rays_per_step = 2 * n * world
+    mrays = rays_per_step * args.steps / elapsed / 1e6
+
+    # hit ids of the last launch (incoherent set) for the parity spot check below
+    gpu_id1 = out_i[1].cpu().numpy().copy()
+    gpu_t = out_f[0].cpu().numpy().copy()
+
+    # ---- path-tracing leg: samples/s at 1920x1080 (BASELINE.json configs[2] shape)
+    render = None
+    if args.render_passes > 0:
+        ctx.set_camera(scene.camera)
+        ctx.render(1)  # warm-up pass
+        ctx.reset_accumulation()
+        s0 = ctx.stats()
+        barrier()
+        r0 = time.perf_counter()
+        ctx.render(args.render_passes)
+        barrier()
+        r_el = time.perf_counter() - r0
+        if world > 1:
+            t = torch.tensor([r_el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            r_el = float(t.item())
+        s1 = ctx.stats()
+        traced = (s1["closest_rays"] - s0["closest_rays"]) + (s1["shadow_rays"] - s0["shadow_rays"])
+        render = {
+            "workload": f"sponza_class {W}x{H}, depth {args.render_depth}, point+env NEE, {args.render_passes} passes per GPU",
+            "samples_per_sec": W * H * args.render_passes * world / r_el,
+            "mrays_per_sec": traced * world / r_el / 1e6,
+            "ms_per_pass": r_el / args.render_passes * 1e3,
+        }
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- CPU side: the oracle on the same ray sets (rank 0): traversal
+    # counters for the algorithmic byte count, the CPU baseline, and a
+    # full-size bit-exact parity check of the hit ids.
+    roofline = None
+    cpu_baseline = None
+    parity = None
+    if not args.no_cpu_baseline:
+        from oracle.binding import OracleScene
+        threads = args.cpu_threads or max(1, min(16, len(os.sched_getaffinity(0))))
+        orc = OracleScene(scene)
+        counts = {}
+        cpu_s = 0.0
+        for k in ("coherent", "incoherent"):
+            c0 = time.perf_counter()
+            rt, rid0, rid1, ru, rv, cnt = orc.intersect(sets[k], counters=True, threads=threads)
+            cpu_s += time.perf_counter() - c0
+            counts[k] = cnt
+            if k == "incoherent":
+                parity = {"set": "incoherent", "rays": n,
+                          "id_mismatches": int((rid1 != gpu_id1).sum()),
+                          "dist_bit_mismatches": int((rt.view(np.uint32) != gpu_t.view(np.uint32)).sum())}
+        cpu_baseline = {"value": 2 * n / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                        "sample": f"both full ray sets ({2*n} rays), oracle closest hit, {threads} threads, {cpu_s:.1f} s wall"}
+        tot_bytes = sum(algorithmic_bytes(n, counts[k]["n_inner"], counts[k]["n_tri"]) for k in counts)
+        tot_ms = sum(float(np.mean(kernel_ms[k])) for k in counts)
+        achieved = tot_bytes / (tot_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("k_trace_closest_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "bytes_per_launch": tot_bytes / 2, "avg_launch_ms": tot_ms / 2,
+                    "per_set": {k: {"n_inner_per_ray": counts[k]["n_inner"] / n, "n_tri_per_ray": counts[k]["n_tri"] / n,
+                                    "bytes_per_ray": algorithmic_bytes(n, counts[k]["n_inner"], counts[k]["n_tri"]) / n,
+                                    "kernel_ms": float(np.mean(kernel_ms[k])),
+                                    "mrays_per_sec": n / float(np.mean(kernel_ms[k])) / 1e3} for k in counts}}
+
+    line = {
+        "metric": "Mrays/sec (closest-hit, whole node)", "value": mrays, "unit": "Mrays/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"primary-ray closest hit, sponza_class ({scene.n_triangles} triangles) {W}x{H}: "
+                               f"coherent + incoherent sets of {n} rays per GPU per step",
+                   "rays_per_step": rays_per_step, "bvh": "reference LBVH, 1 triangle per leaf"},
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "render": render,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

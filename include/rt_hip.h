@@ -168,6 +168,8 @@ int rt_lbvh_host(const float* pos, uint32_t pos_stride, const uint32_t* indices,
 uint32_t rt_morton3d(float x, float y, float z);
 
 int rt_get_stats(rt_ctx* ctx, rt_stats* out);
+/* rt_stats.last_trace_ms without the device round trip of rt_get_stats. */
+float rt_last_trace_ms(const rt_ctx* ctx);
 int rt_synchronize(rt_ctx* ctx);
 
 /* Library identity: "rt_hip <version> gfx950". */

@@ -62,7 +62,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_camera", "rt_reset_accumulation", "rt_render",
     "rt_read_film", "rt_film_slab", "rt_copy_film_slab", "rt_unpack_slabs", "rt_trace_closest",
     "rt_trace_occluded", "rt_trace_closest_dev", "rt_trace_occluded_dev", "rt_get_bvh", "rt_get_stats",
-    "rt_synchronize", "rt_version", "rt_lbvh_host", "rt_morton3d",
+    "rt_synchronize", "rt_version", "rt_lbvh_host", "rt_morton3d", "rt_last_trace_ms",
 ]
 
 
@@ -99,9 +99,11 @@ def load_library():
     lib.rt_lbvh_host.argtypes = [fp, C.c_uint32, up, C.c_uint32, ip, ip, fp, ip, ip, ip, ip, ip]
     lib.rt_morton3d.argtypes = [C.c_float, C.c_float, C.c_float]
     for name in EXPORTS:
-        if name not in ("rt_destroy", "rt_last_error", "rt_version", "rt_morton3d"):
+        if name not in ("rt_destroy", "rt_last_error", "rt_version", "rt_morton3d", "rt_last_trace_ms"):
             getattr(lib, name).restype = C.c_int
     lib.rt_morton3d.restype = C.c_uint32
+    lib.rt_last_trace_ms.argtypes = [vp]
+    lib.rt_last_trace_ms.restype = C.c_float
     _lib = lib
     return lib
 
@@ -231,6 +233,9 @@ class Context:
         st = rt_stats()
         self._check(self._lib.rt_get_stats(self._h, C.byref(st)))
         return {k: getattr(st, k) for k, _ in rt_stats._fields_}
+
+    def last_trace_ms(self) -> float:
+        return float(self._lib.rt_last_trace_ms(self._h))
 
     def synchronize(self):
         self._check(self._lib.rt_synchronize(self._h))

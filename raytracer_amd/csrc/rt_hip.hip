@@ -700,6 +700,8 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     return RT_OK;
 }
 
+float rt_last_trace_ms(const rt_ctx* c) { return c ? c->last_trace_ms : 0.f; }
+
 int rt_synchronize(rt_ctx* c) {
     if (!c) return RT_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
