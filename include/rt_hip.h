@@ -132,6 +132,13 @@ int rt_copy_film_slab(rt_ctx* ctx, void* device_dst, uint64_t n_floats);
 int rt_unpack_slabs(int32_t width, int32_t height, int32_t tile_size, int32_t world,
                     const float* slabs_host, uint64_t slab_floats_per_rank, float* rgba_out);
 
+/* Host-side inverse of rt_unpack_slabs for one rank: packs that rank's tiles
+ * of a width*height*4 film into slab order.  rt_slab_floats gives the slab
+ * size (floats) a rank holds.  Neither touches a device. */
+uint64_t rt_slab_floats(int32_t width, int32_t height, int32_t tile_size, int32_t rank, int32_t world);
+int rt_pack_slab(int32_t width, int32_t height, int32_t tile_size, int32_t rank, int32_t world,
+                 const float* rgba_in, float* slab_out);
+
 /* BVH::intersect (src/scene/BVH.cpp:49-61,129-170) over n rays.  rays: six
  * planes ox,oy,oz,dx,dy,dz of n floats (host memory).  Outputs (host, n
  * entries each): dist (+inf on a miss), id0 = model index, id1 = index-buffer

@@ -62,7 +62,7 @@ EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_camera", "rt_reset_accumulation", "rt_render",
     "rt_read_film", "rt_film_slab", "rt_copy_film_slab", "rt_unpack_slabs", "rt_trace_closest",
     "rt_trace_occluded", "rt_trace_closest_dev", "rt_trace_occluded_dev", "rt_get_bvh", "rt_get_stats",
-    "rt_synchronize", "rt_version", "rt_lbvh_host", "rt_morton3d", "rt_last_trace_ms",
+    "rt_synchronize", "rt_version", "rt_lbvh_host", "rt_morton3d", "rt_last_trace_ms", "rt_slab_floats", "rt_pack_slab",
 ]
 
 
@@ -99,9 +99,12 @@ def load_library():
     lib.rt_lbvh_host.argtypes = [fp, C.c_uint32, up, C.c_uint32, ip, ip, fp, ip, ip, ip, ip, ip]
     lib.rt_morton3d.argtypes = [C.c_float, C.c_float, C.c_float]
     for name in EXPORTS:
-        if name not in ("rt_destroy", "rt_last_error", "rt_version", "rt_morton3d", "rt_last_trace_ms"):
+        if name not in ("rt_destroy", "rt_last_error", "rt_version", "rt_morton3d", "rt_last_trace_ms", "rt_slab_floats"):
             getattr(lib, name).restype = C.c_int
     lib.rt_morton3d.restype = C.c_uint32
+    lib.rt_slab_floats.restype = C.c_uint64
+    lib.rt_slab_floats.argtypes = [C.c_int32] * 5
+    lib.rt_pack_slab.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, fp]
     lib.rt_last_trace_ms.argtypes = [vp]
     lib.rt_last_trace_ms.restype = C.c_float
     _lib = lib
@@ -264,3 +267,19 @@ def lbvh_host(scene: Scene):
     if rc != 0:
         raise RtError(rc, "rt_lbvh_host failed")
     return (md.value, boxes, *arrs)
+
+
+def slab_floats(width: int, height: int, tile_size: int, rank: int, world: int) -> int:
+    return int(load_library().rt_slab_floats(width, height, tile_size, rank, world))
+
+
+def pack_slab(film: np.ndarray, tile_size: int, rank: int, world: int) -> np.ndarray:
+    """This rank's tiles of a (H, W, 4) film in slab order (host only)."""
+    lib = load_library()
+    film = np.ascontiguousarray(film, np.float32)
+    h, w = film.shape[:2]
+    out = np.empty(slab_floats(w, h, tile_size, rank, world), np.float32)
+    rc = lib.rt_pack_slab(w, h, tile_size, rank, world, _fptr(film), _fptr(out))
+    if rc != 0:
+        raise RtError(rc, "rt_pack_slab failed")
+    return out

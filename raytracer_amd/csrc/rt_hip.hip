@@ -602,6 +602,36 @@ int rt_unpack_slabs(int32_t W, int32_t H, int32_t tile, int32_t world, const flo
     return RT_OK;
 }
 
+uint64_t rt_slab_floats(int32_t W, int32_t H, int32_t tile, int32_t rank, int32_t world) {
+    if (W <= 0 || H <= 0 || world <= 0 || rank < 0 || rank >= world) return 0;
+    if (tile <= 0) tile = 64;
+    const uint32_t n_tiles = (uint32_t)((W + tile - 1) / tile) * (uint32_t)((H + tile - 1) / tile);
+    const uint32_t local = n_tiles > (uint32_t)rank ? (n_tiles - rank + world - 1) / world : 0;
+    return (uint64_t)local * tile * tile * 4;
+}
+
+int rt_pack_slab(int32_t W, int32_t H, int32_t tile, int32_t rank, int32_t world, const float* rgba_in, float* slab_out) {
+    if (!rgba_in || !slab_out || W <= 0 || H <= 0 || world <= 0 || rank < 0 || rank >= world) return RT_ERR_ARG;
+    if (tile <= 0) tile = 64;
+    if (tile % 8) return RT_ERR_ARG;
+    const int tiles_x = (W + tile - 1) / tile, tiles_y = (H + tile - 1) / tile;
+    const uint32_t n_tiles = (uint32_t)tiles_x * tiles_y;
+    const int bpr = tile / 8;
+    uint32_t k = 0;
+    for (uint32_t t = rank; t < n_tiles; t += world, ++k) {
+        int tx = t % tiles_x, ty = t / tiles_x;
+        for (int i = 0; i < tile * tile; ++i) {
+            int blk = i >> 6, li = i & 63;
+            int x = tx * tile + (blk % bpr) * 8 + (li & 7);
+            int y = ty * tile + (blk / bpr) * 8 + (li >> 3);
+            float* dst = slab_out + ((size_t)k * tile * tile + i) * 4;
+            if (x < W && y < H) memcpy(dst, rgba_in + ((size_t)y * W + x) * 4, 4 * sizeof(float));
+            else memset(dst, 0, 4 * sizeof(float));
+        }
+    }
+    return RT_OK;
+}
+
 int rt_trace_closest_dev(rt_ctx* c, uint32_t n, const float* d_rays, float* d_t, int32_t* d_id0, int32_t* d_id1, float* d_u,
                          float* d_v, uint32_t repeat) {
     if (!c || !d_rays || !d_t || !d_id0 || !d_id1 || !d_u || !d_v) return RT_ERR_ARG;

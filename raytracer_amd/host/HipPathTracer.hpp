@@ -1,0 +1,102 @@
+// HipPathTracer: the host-side stand-in for the reference's Integrator
+// (src/cpu/Integrator.hpp:14-58) that drives the gfx950 library through its
+// C-ABI instead of a CPU tile pool.  Same call protocol as the reference app
+// uses (src/app/App.cpp:40-43,92-93,113-121):
+//
+//     HipPathTracer pt(scene_desc, width, height);     // Integrator(device, scene, w, h)
+//     pt.nextFrame(pos, right, forward); pt.run();     // App.cpp:92-93
+//     ... per UI tick:
+//     if (pt.isUpdateFinish()) { pt.sync(dst); pt.nextFrame(pos, right, forward); }   // App.cpp:116-119
+//     pt.finish();
+//
+// It needs no Mango/glm: the scene arrives as the flat arrays BVH::runLBVH
+// flattens to (rt_scene_desc) and the camera as the three vectors nextFrame
+// snapshots (src/cpu/Integrator.cpp:85-92).  In the reference tree the same
+// class body becomes `class HipPathTracer : public Integrator`, with the
+// arrays filled from Scene::models() and sync() writing the staging buffer.
+#pragma once
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+
+class HipPathTracer {
+   public:
+    HipPathTracer(const rt_scene_desc& scene, int width, int height, int max_depth = 4, uint64_t seed = 0, int device = 0)
+        : _width(width), _height(height) {
+        rt_params p{};
+        p.width = width; p.height = height; p.max_depth = max_depth; p.tile_size = 64;
+        p.seed = seed; p.device = device; p.rank = 0; p.world = 1;
+        if (rt_create(&scene, &p, &_ctx) != RT_OK) throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
+        _frame.assign((size_t)width * height * 4, 0.f);
+    }
+    ~HipPathTracer() {
+        finish();
+        if (_renderThread && _renderThread->joinable()) _renderThread->join();
+        rt_destroy(_ctx);
+    }
+    HipPathTracer(const HipPathTracer&) = delete;
+    HipPathTracer& operator=(const HipPathTracer&) = delete;
+
+    // src/cpu/Integrator.cpp:69-79: the render loop; one library pass per update()
+    void run() {
+        _renderThread = std::make_shared<std::thread>([this]() {
+            while (_isRun) {
+                if (!_isFinish) {
+                    update();
+                    _isFinish = true;
+                } else {
+                    std::this_thread::yield();
+                }
+            }
+        });
+    }
+    bool isUpdateFinish() const { return _isFinish; }  // src/cpu/Integrator.cpp:81-83
+
+    // src/cpu/Integrator.cpp:85-92: snapshot the camera; up = normalize(cross(right, forward))
+    void nextFrame(const float pos[3], const float right[3], const float forward[3]) {
+        float c[3] = {right[1] * forward[2] - forward[1] * right[2], right[2] * forward[0] - forward[2] * right[0],
+                      right[0] * forward[1] - forward[0] * right[1]};
+        float inv = 1.0f / std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        for (int i = 0; i < 3; ++i) { _pos[i] = pos[i]; _right[i] = right[i]; _forward[i] = forward[i]; _up[i] = c[i] * inv; }
+        _isFinish = false;
+    }
+    // src/cpu/Integrator.cpp:94-97
+    void finish() {
+        _isRun = false;
+        while (!_isFinish && _renderThread) std::this_thread::yield();
+    }
+    // src/cpu/Integrator.cpp:21-24: hand the finished frame over (width*height*4 floats)
+    void sync(float* rgba_dst) { std::memcpy(rgba_dst, _frame.data(), _frame.size() * sizeof(float)); }
+
+    uint64_t frames() const { return _frames; }
+    rt_ctx* context() { return _ctx; }
+
+   protected:
+    // src/cpu/Integrator.cpp:26-67 with the tile pool replaced by one rt_render pass
+    void update() {
+        if (rt_set_camera(_ctx, _pos, _right, _up, _forward) != RT_OK || rt_render(_ctx, 1) != RT_OK ||
+            rt_read_film(_ctx, _frame.data()) != RT_OK) {
+            _error = rt_last_error(_ctx);
+            _isRun = false;
+            return;
+        }
+        _frames++;
+    }
+
+    rt_ctx* _ctx = nullptr;
+    int _width, _height;
+    float _pos[3]{}, _right[3]{}, _forward[3]{}, _up[3]{};
+    std::vector<float> _frame;
+    uint64_t _frames = 0;
+    std::string _error;
+    std::shared_ptr<std::thread> _renderThread;
+    std::atomic_bool _isFinish{true};
+    std::atomic_bool _isRun{true};
+};

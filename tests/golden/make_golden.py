@@ -1,0 +1,52 @@
+"""Generates tests/golden/*.npz from the CPU oracle (the reference itself
+holds no fixtures and cannot be built here).  The vectors freeze the oracle's
+behaviour so that later edits to it, or to the scenes, are caught; they pin
+neither side to the reference.  Run from the repository root:
+    python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import binding as ob  # noqa: E402
+from raytracer_amd import scenes  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    L = ob.lib()
+    # 1. Cornell box, 32x32: primary hits and a 2-pass film (seed 0, depth 4)
+    s = scenes.cornell_box(env=True)
+    o = ob.OracleScene(s)
+    rays = ob.camera_rays(s.camera, 32, 32)
+    t, id0, id1, u, v = o.intersect(rays)
+    film, cnt = o.render(s.camera, 32, 32, 4, 0, 2, threads=1)
+    inc = scenes.incoherent_rays(s, 2048, seed=9)
+    ti, i0, i1, ui, vi = o.intersect(inc)
+    occ = o.occluded(inc)
+    np.savez_compressed(os.path.join(HERE, "cornell_env_32.npz"), t=t, id0=id0, id1=id1, u=u, v=v, film=film,
+                        closest=np.uint64(cnt["closest"]), shadow=np.uint64(cnt["shadow"]),
+                        inc_t=ti, inc_id0=i0, inc_id1=i1, inc_u=ui, inc_v=vi, inc_occ=occ)
+    # 2. sampler values
+    keys = [(seed, pix, ps, dim) for seed in (0, 7) for pix in (0, 1, 1000, 2073599) for ps in (0, 1, 1023) for dim in (0, 1, 65)]
+    vals = np.array([L.orc_rng_u01(*k) for k in keys], np.float32)
+    np.savez_compressed(os.path.join(HERE, "rng.npz"), keys=np.array(keys, np.uint64), vals=vals)
+    # 3. small atrium: tree digest + hits
+    a = scenes.sponza_class(detail=0.2, env_size=(32, 16))
+    oa = ob.OracleScene(a)
+    boxes, left, right, tri, model, leaf = oa.bvh_nodes()
+    ra = ob.camera_rays(a.camera, 48, 27)
+    ta, a0, a1, ua, va, c = oa.intersect(ra, counters=True)
+    np.savez_compressed(os.path.join(HERE, "atrium_d02.npz"), n_tris=np.int64(a.n_triangles), left=left, right=right, tri=tri,
+                        box_sum=boxes.astype(np.float64).sum(0), t=ta, id0=a0, id1=a1, u=ua, v=va,
+                        n_inner=np.uint64(c["n_inner"]), n_tri=np.uint64(c["n_tri"]))
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+"""CPU-side checks of the product's host code: the C-ABI library loads and
+exports what include/rt_hip.h declares, argument validation, the host LBVH
+builder against the oracle's tree, and the tile-slab pack/unpack pair."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from raytracer_amd import api, scenes
+from tests.test_oracle_kats import soup
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "rt_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = api.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in rt_hip.h but not exported"
+    assert set(api.EXPORTS) == declared
+    assert b"gfx950" in lib.rt_version()
+
+
+def test_create_rejects_bad_arguments_before_touching_a_device():
+    lib = api.load_library()
+    h = C.c_void_p()
+    assert lib.rt_create(None, None, C.byref(h)) == -1
+    d, p = api.rt_scene_desc(), api.rt_params()
+    assert lib.rt_create(C.byref(d), C.byref(p), C.byref(h)) == -1
+    assert b"positions" in lib.rt_last_error(None)
+    assert not h.value
+
+
+def test_create_without_gpu_fails_loudly(cornell):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.RtError) as e:
+        api.Context(cornell, 32, 32)
+    assert e.value.code == -3
+
+
+def test_null_context_calls_return_arg_error():
+    lib = api.load_library()
+    assert lib.rt_render(None, 1) == -1
+    assert lib.rt_get_stats(None, None) == -1
+    assert lib.rt_read_film(None, None) == -1
+    lib.rt_destroy(None)  # no-op
+
+
+def _random_soup(n, seed, dup=0, flat=False):
+    rng = np.random.default_rng(seed)
+    c = rng.uniform(-5, 5, (n, 1, 3))
+    if flat:
+        c[..., 1] = 0.0
+    tris = c + rng.uniform(-0.3, 0.3, (n, 3, 3)) * (np.array([1, 0, 1]) if flat else 1)
+    tris = [tuple(map(tuple, t)) for t in tris]
+    tris += tris[:dup]  # exact duplicates: identical Morton codes
+    return soup(tris, models=list(rng.integers(0, 3, len(tris))))
+
+
+@pytest.mark.parametrize("maker", [
+    lambda: scenes.cornell_box(),
+    lambda: scenes.sponza_class(detail=0.3, env_size=(16, 8)),
+    lambda: _random_soup(500, 1),
+    lambda: _random_soup(300, 2, dup=40),
+    lambda: _random_soup(64, 3, flat=True),   # flat axis: 0/0 in the Morton normalisation
+    lambda: _random_soup(1, 4),
+    lambda: _random_soup(2, 5),
+])
+def test_host_lbvh_matches_oracle_tree(maker):
+    s = maker()
+    md, boxes, left, right, tri, model, leaf = api.lbvh_host(s)
+    o = ob.OracleScene(s)
+    n, depth = o.bvh_info()
+    rb, rl, rr, rtri, rmodel, rleaf = o.bvh_nodes()
+    assert n == 2 * s.n_triangles - 1 == len(left)
+    assert md == depth
+    assert np.array_equal(leaf, rleaf)
+    inner = leaf == 0
+    assert np.array_equal(left[inner], rl[inner]) and np.array_equal(right[inner], rr[inner])
+    assert np.array_equal(tri[~inner], rtri[~inner]) and np.array_equal(model[~inner], rmodel[~inner])
+    assert np.array_equal(boxes, rb)  # == on floats: -0 and +0 compare equal
+    # every triangle is in exactly one leaf
+    assert sorted(tri[~inner].tolist()) == list(range(0, 3 * s.n_triangles, 3))
+
+
+def test_morton_matches_oracle():
+    lib, L = api.load_library(), ob.lib()
+    rng = np.random.default_rng(0)
+    for x, y, z in rng.uniform(-0.2, 1.2, (2000, 3)).astype(np.float32):
+        assert lib.rt_morton3d(x, y, z) == L.orc_morton3d(x, y, z)
+    assert lib.rt_morton3d(float("nan"), 0.5, 0.5) == L.orc_morton3d(float("nan"), 0.5, 0.5)
+
+
+@pytest.mark.parametrize("w,h,tile,world", [(100, 70, 64, 1), (100, 70, 64, 2), (130, 130, 32, 3), (64, 64, 64, 4),
+                                             (1920, 1080, 64, 8), (17, 9, 8, 2)])
+def test_slab_pack_unpack_round_trip(w, h, tile, world):
+    rng = np.random.default_rng(w * h + world)
+    film = rng.random((h, w, 4), np.float32)
+    sizes = [api.slab_floats(w, h, tile, r, world) for r in range(world)]
+    n_tiles = -(-w // tile) * -(-h // tile)
+    assert sum(sizes) == n_tiles * tile * tile * 4
+    per = max(sizes)
+    slabs = np.zeros((world, per), np.float32)
+    for r in range(world):
+        slabs[r, : sizes[r]] = api.pack_slab(film, tile, r, world)
+    out = api.unpack_slabs(w, h, tile, world, slabs, per)
+    assert np.array_equal(out, film)
+    # a rank's slab holds only its own tiles: zeroing another rank's slab
+    # leaves this rank's pixels intact
+    if world > 1:
+        slabs2 = slabs.copy()
+        slabs2[1] = 0
+        out2 = api.unpack_slabs(w, h, tile, world, slabs2, per)
+        ty, tx = np.mgrid[0:h, 0:w]
+        owner = ((ty // tile) * -(-w // tile) + tx // tile) % world
+        assert np.array_equal(out2[owner != 1], film[owner != 1])
+        assert not out2[owner == 1].any()
+
+
+def test_incoherent_rays_are_seeded_and_unit_length(cornell):
+    a = scenes.incoherent_rays(cornell, 1000, seed=3)
+    b = scenes.incoherent_rays(cornell, 1000, seed=3)
+    c = scenes.incoherent_rays(cornell, 1000, seed=4)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+    assert np.allclose(np.linalg.norm(a[3:], axis=0), 1.0, atol=1e-5)
+    lo, hi = cornell.pos.min(0), cornell.pos.max(0)
+    assert (a[:3].T >= lo - 1e-6).all() and (a[:3].T <= hi + 1e-6).all()
+
+
+def test_camera_rays_numpy_equals_oracle(cornell):
+    for w, h in ((64, 64), (33, 17)):
+        assert np.array_equal(scenes.camera_rays_numpy(cornell.camera, w, h), ob.camera_rays(cornell.camera, w, h))
+    cam = scenes.make_camera((1, 2, 3), (0.3, -0.2, 0.9))
+    assert np.array_equal(scenes.camera_rays_numpy(cam, 40, 30), ob.camera_rays(cam, 40, 30))
+
+
+def test_sponza_class_shape():
+    s = scenes.sponza_class(env_size=(16, 8))
+    assert abs(s.n_triangles - 262144) / 262144 < 0.05
+    ext = s.pos.max(0) - s.pos.min(0)
+    assert ext == pytest.approx([37, 15, 23], abs=0.6)
+    assert 15 <= s.n_models <= 30
+    assert s.tri_model.max() == s.n_models - 1
