@@ -13,7 +13,8 @@ import numpy as np
 
 from .scenes import LIGHT_ENV, Camera, Scene
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_hip.so")
+# RT_HIP_LIB selects another build of the same library (kernel A/B runs)
+_LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_hip.so")
 _lib = None
 
 

@@ -63,7 +63,7 @@ uint32_t find_split(const std::vector<Prim>& p, uint32_t start, uint32_t end) {
 }  // namespace
 
 void build_lbvh(const float* pos, uint32_t stride, const uint32_t* indices, uint32_t n_indices,
-                const int32_t* tri_model, LbvhResult& out) {
+                const int32_t* tri_model, LbvhResult& out, size_t bfs_prefix) {
     const uint32_t T = n_indices / 3;
     auto P = [&](uint32_t vi) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(pos) + (size_t)vi * stride); };
     const float inf = std::numeric_limits<float>::infinity();
@@ -179,6 +179,41 @@ void build_lbvh(const float* pos, uint32_t stride, const uint32_t* indices, uint
         d.pad[0] = d.pad[1] = 0;
     }
     out.root_link = T ? link[0] : 0;
+
+    // Renumber the inner nodes: the first bfs_prefix in breadth-first order
+    // from the root (a set of top-most nodes, which the traversal kernels keep
+    // in LDS), the rest in the order above, where a node's left child follows
+    // it directly (parent and near child often share a 128-byte line).
+    const size_t NI = out.nodes.size();
+    if (NI > 1 && out.root_link >= 0 && bfs_prefix > 0) {
+        std::vector<int32_t> renum(NI, -1);
+        std::vector<int32_t> order;
+        order.reserve(NI);
+        order.push_back(out.root_link);
+        renum[out.root_link] = 0;
+        for (size_t head = 0; head < order.size() && order.size() < bfs_prefix; ++head) {
+            const DevNode& d = out.nodes[order[head]];
+            for (int32_t ch : {d.left, d.right})
+                if (ch >= 0 && renum[ch] < 0 && order.size() < bfs_prefix) {
+                    renum[ch] = (int32_t)order.size();
+                    order.push_back(ch);
+                }
+        }
+        for (size_t i = 0; i < NI; ++i)
+            if (renum[i] < 0) {
+                renum[i] = (int32_t)order.size();
+                order.push_back((int32_t)i);
+            }
+        std::vector<DevNode> moved(NI);
+        for (size_t k = 0; k < NI; ++k) {
+            DevNode d = out.nodes[order[k]];
+            if (d.left >= 0) d.left = renum[d.left];
+            if (d.right >= 0) d.right = renum[d.right];
+            moved[k] = d;
+        }
+        out.nodes.swap(moved);
+        out.root_link = 0;
+    }
 }
 
 }  // namespace rt

@@ -2,6 +2,7 @@
 // (src/scene/BVH.cpp:189-336) in the reference's node numbering, plus the
 // compact device layout the traversal kernels read.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
@@ -47,8 +48,10 @@ struct LbvhResult {
 };
 
 // pos: strided vertex positions; indices already offset; tri_model per triangle.
+// The first bfs_prefix inner nodes of out.nodes are the top-most ones in
+// breadth-first order (the part the kernels stage in LDS).
 void build_lbvh(const float* pos, uint32_t pos_stride_bytes, const uint32_t* indices, uint32_t n_indices,
-                const int32_t* tri_model, LbvhResult& out);
+                const int32_t* tri_model, LbvhResult& out, size_t bfs_prefix);
 
 uint32_t expand_bits(uint32_t v);
 uint32_t morton3d(float x, float y, float z);

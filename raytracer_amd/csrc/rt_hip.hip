@@ -30,8 +30,10 @@ struct EnvTables {
 struct rt_ctx {
     int device = 0;
     int num_cu = 256;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // main stream: extend / shade chain, rt_trace_*
+    hipStream_t stream_b = nullptr;        // shadow / accumulate chain of a pass
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<hipEvent_t> ev_shade, ev_acc;  // per bounce: shade(d) done on the main stream / accumulate(d) done on stream_b
     std::string err;
 
     rt_params params{};
@@ -58,13 +60,22 @@ struct rt_ctx {
     std::vector<void*> allocs;
     PathBuffers pb{};
     uint32_t* d_q0 = nullptr;
-    uint32_t* d_q[2] = {nullptr, nullptr};
-    uint32_t* d_counts = nullptr;       // [max_depth+1] queue counts, then [max_depth][L] shadow counts
+    uint32_t* d_q[3] = {nullptr, nullptr, nullptr};  // path queues, rotating: bounce d+1 is written while accumulate(d) still reads bounce d
+    // [D+1] queue counts, then [D] shadow-queue counts
+    uint32_t* d_counts = nullptr;
     uint32_t* d_counts_init = nullptr;  // template copied in at the start of a pass
     uint32_t n_counts = 0;
-    ShadowQueue* d_sq = nullptr;
-    std::vector<ShadowQueue> h_sq;
+    ShadowQueue sq[2]{};                   // by bounce parity
+    float* vpos[2] = {nullptr, nullptr};   // shaded-vertex positions, by bounce parity
+    uint32_t* d_pass_deferred_b = nullptr; // deferred list of the shadow launches
     unsigned long long* d_raystats = nullptr;  // [0] closest, [1] shadow
+    TraceWork* d_work = nullptr;               // work counters of the rt_trace_* launches
+    uint32_t* d_deferred = nullptr;            // rays handed to the exact follow-up launch (rt_trace_*)
+    uint32_t deferred_cap = 0;
+    TraceWork* d_pass_work = nullptr;          // [D] closest + [D] shadow launches of a pass
+    uint32_t n_pass_work = 0;
+    uint32_t* d_pass_deferred = nullptr;       // n_slots entries, reused by the launches of a pass
+    uint32_t grid_exact = 8;                   // blocks of the (almost always empty) follow-up launches
     uint32_t* d_slot_pixel = nullptr;
     std::vector<uint32_t> h_slot_pixel;
 
@@ -170,7 +181,7 @@ int build_env(rt_ctx* c, const rt_light& src, DevLight& dst, EnvTables& tab) {
 }
 
 uint32_t grid_for(const rt_ctx* c, uint32_t n) {
-    uint32_t g = (n + RT_BLOCK - 1) / RT_BLOCK;
+    uint32_t g = (n + RT_TBLOCK - 1) / RT_TBLOCK;
     if (g > c->grid_trace) g = c->grid_trace;
     return g ? g : 1;
 }
@@ -185,13 +196,27 @@ int ensure_trace_staging(rt_ctx* c, uint32_t n) {
     return RT_OK;
 }
 
+// The deferred list of the rt_trace_* launches must be able to hold every ray.
+int ensure_deferred(rt_ctx* c, uint32_t n) {
+    if (n <= c->deferred_cap) return RT_OK;
+    int r = dev_alloc(c, &c->d_deferred, n);
+    if (r) return r;
+    c->deferred_cap = n;
+    return RT_OK;
+}
+
 int launch_closest(rt_ctx* c, uint32_t n, const float* d_rays, float* d_t, int32_t* d_id0, int32_t* d_id1, float* d_u,
                    float* d_v, uint32_t repeat) {
     if (repeat == 0) repeat = 1;
+    if (int r = ensure_deferred(c, n)) return r;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    for (uint32_t r = 0; r < repeat; ++r)
-        hipLaunchKernelGGL(k_trace_closest, dim3(grid_for(c, n)), dim3(RT_BLOCK), 0, c->stream, c->ts, d_rays, n, nullptr, nullptr,
-                           n, d_t, d_id0, d_id1, d_u, d_v, c->d_raystats);
+    for (uint32_t r = 0; r < repeat; ++r) {
+        HIP_TRY(c, hipMemsetAsync(c->d_work, 0, sizeof(TraceWork), c->stream));
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
+                           c->d_deferred, d_t, d_id0, d_id1, d_u, d_v, c->d_raystats);
+        hipLaunchKernelGGL(k_trace_closest<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
+                           c->d_deferred, d_t, d_id0, d_id1, d_u, d_v, c->d_raystats);
+    }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventSynchronize(c->ev1));
@@ -203,9 +228,15 @@ int launch_closest(rt_ctx* c, uint32_t n, const float* d_rays, float* d_t, int32
 
 int launch_occluded(rt_ctx* c, uint32_t n, const float* d_rays, int32_t* d_status, uint32_t repeat) {
     if (repeat == 0) repeat = 1;
+    if (int r = ensure_deferred(c, n)) return r;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    for (uint32_t r = 0; r < repeat; ++r)
-        hipLaunchKernelGGL(k_trace_occluded, dim3(grid_for(c, n)), dim3(RT_BLOCK), 0, c->stream, c->ts, d_rays, n, n, d_status);
+    for (uint32_t r = 0; r < repeat; ++r) {
+        HIP_TRY(c, hipMemsetAsync(c->d_work, 0, sizeof(TraceWork), c->stream));
+        hipLaunchKernelGGL(k_trace_occluded<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
+                           c->d_deferred, d_status);
+        hipLaunchKernelGGL(k_trace_occluded<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
+                           c->d_deferred, d_status);
+    }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipEventSynchronize(c->ev1));
@@ -227,25 +258,49 @@ int run_pass(rt_ctx* c) {
         return z ^ (z >> 31);
     }();
     HIP_TRY(c, hipMemcpyAsync(c->d_counts, c->d_counts_init, c->n_counts * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_pass_work, 0, c->n_pass_work * sizeof(TraceWork), c->stream));
     const uint32_t gslots = (n + RT_BLOCK - 1) / RT_BLOCK;
     hipLaunchKernelGGL(k_generate, dim3(gslots), dim3(RT_BLOCK), 0, c->stream, c->pb, c->cam);
     const uint32_t gtrace = grid_for(c, c->n_valid);
     const uint32_t gshade = std::min<uint32_t>(gslots, (uint32_t)c->num_cu * 8u);
+    // Two chains share the GPU: the main stream runs extend(d) -> shade(d),
+    // stream_b runs shadow(d) -> accumulate(d).  shadow(d) only needs what
+    // shade(d) wrote (queue, contributions and vertex positions of parity d&1),
+    // so it overlaps extend(d+1)/shade(d+1): the long serial tail of one
+    // persistent traversal launch is covered by the bulk of the other.
     const uint32_t* qin = c->d_q0;
     for (int d = 0; d < D; ++d) {
+        const int p = d & 1;
         uint32_t* cnt_in = c->d_counts + d;
         uint32_t* cnt_out = c->d_counts + d + 1;
-        uint32_t* qout = c->d_q[d & 1];
-        hipLaunchKernelGGL(k_trace_closest, dim3(gtrace), dim3(RT_BLOCK), 0, c->stream, c->ts, c->pb.rays, n, qin, cnt_in, 0u,
-                           c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v, c->d_raystats);
-        uint32_t* sqc = c->d_counts + (D + 1) + (size_t)d * L;
-        hipLaunchKernelGGL(k_shade, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, c->pb, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
-                           qout, cnt_out, c->d_sq, sqc);
-        for (int l = 0; l < L; ++l)
-            hipLaunchKernelGGL(k_shadow, dim3(gtrace), dim3(RT_BLOCK), 0, c->stream, c->ts, c->pb, c->h_sq[l], sqc + l,
-                               c->d_raystats + 1);
+        uint32_t* qout = c->d_q[(d + 1) % 3];
+        TraceWork* work = c->d_pass_work;
+        PathBuffers pbd = c->pb;
+        pbd.vpos = c->vpos[p];
+        hipLaunchKernelGGL(k_extend<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.rays, n, qin, cnt_in, work + d,
+                           c->d_pass_deferred, c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v, c->d_raystats);
+        hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.rays, n, qin, cnt_in,
+                           work + d, c->d_pass_deferred, c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v,
+                           c->d_raystats);
+        uint32_t* sqc = c->d_counts + (D + 1) + d;
+        // shade(d) overwrites the parity-p buffers that shadow/accumulate(d-2) read
+        if (L > 0 && d >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_acc[d - 2], 0));
+        hipLaunchKernelGGL(k_shade, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in, qout,
+                           cnt_out, c->sq[p], sqc);
+        if (L > 0) {
+            HIP_TRY(c, hipEventRecord(c->ev_shade[d], c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(c->stream_b, c->ev_shade[d], 0));
+            TraceWork* w = work + D + d;
+            hipLaunchKernelGGL(k_shadow<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], sqc, w,
+                               c->d_pass_deferred_b, c->d_raystats + 1);
+            hipLaunchKernelGGL(k_shadow<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], sqc, w,
+                               c->d_pass_deferred_b, c->d_raystats + 1);
+            hipLaunchKernelGGL(k_accumulate, dim3(gshade), dim3(RT_BLOCK), 0, c->stream_b, pbd, c->sq[p], L, qin, cnt_in);
+            HIP_TRY(c, hipEventRecord(c->ev_acc[d], c->stream_b));
+        }
         qin = qout;
     }
+    if (L > 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_acc[D - 1], 0));
     hipLaunchKernelGGL(k_film, dim3(gslots), dim3(RT_BLOCK), 0, c->stream, c->pb, (float)c->frames);
     HIP_TRY(c, hipGetLastError());
     c->frames++;
@@ -264,7 +319,11 @@ void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
     for (void* p : c->allocs) (void)hipFree(p);
+    for (hipEvent_t e : c->ev_shade) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_acc) (void)hipEventDestroy(e);
+    if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -331,32 +390,45 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
+    for (int d = 0; d < pr->max_depth; ++d) {
+        hipEvent_t e1 = nullptr, e2 = nullptr;
+        HIP_TRY(c, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        c->ev_shade.push_back(e1);
+        HIP_TRY(c, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        c->ev_acc.push_back(e2);
+    }
     HIP_TRY(c, hipEventCreate(&c->ev0));
     HIP_TRY(c, hipEventCreate(&c->ev1));
 
     // ---- BVH
     auto t0 = std::chrono::steady_clock::now();
-    build_lbvh(sd->pos, sd->pos_stride ? sd->pos_stride : 12, sd->indices, sd->n_indices, sd->tri_model, c->bvh);
+    build_lbvh(sd->pos, sd->pos_stride ? sd->pos_stride : 12, sd->indices, sd->n_indices, sd->tri_model, c->bvh, RT_TOP_NODES);
     c->bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     int r;
     if ((r = dev_upload(c, &c->d_nodes, reinterpret_cast<const float4*>(c->bvh.nodes.data()), c->bvh.nodes.size() * 4))) return r;
     if ((r = dev_upload(c, &c->d_tris, reinterpret_cast<const float4*>(c->bvh.tris.data()), c->bvh.tris.size() * 3))) return r;
 
+    // persistent traversal grid: as many workgroups per CU as LDS and registers admit
     int bpc = 0;
-    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_trace_closest, RT_BLOCK, 0));
+    HIP_TRY(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, k_extend<false>, RT_TBLOCK, 0));
     if (bpc < 1) bpc = 1;
-    if (bpc > 8) bpc = 8;
     c->grid_trace = (uint32_t)c->num_cu * (uint32_t)bpc;
+    c->grid_exact = 8;
     const uint32_t ovf_levels = (uint32_t)std::max(1, c->bvh.max_depth + 2 - RT_STACK_LDS);
-    const uint32_t ovf_stride = c->grid_trace * RT_BLOCK;
+    const uint32_t ovf_stride = c->grid_trace * RT_TBLOCK;
     if ((r = dev_alloc(c, &c->d_ovf, (size_t)ovf_levels * ovf_stride))) return r;
     c->ts.nodes = c->d_nodes;
     c->ts.tris = c->d_tris;
     c->ts.root_link = c->bvh.root_link;
+    c->ts.n_nodes = (int32_t)c->bvh.nodes.size();
     for (int k = 0; k < 3; ++k) { c->ts.rmin[k] = c->bvh.root_min[k]; c->ts.rmax[k] = c->bvh.root_max[k]; }
     c->ts.ovf = c->d_ovf;
     c->ts.ovf_stride = ovf_stride;
     c->ts.ovf_levels = ovf_levels;
+    c->ts.tame = 1;
+    for (int k = 0; k < 3; ++k)
+        if (!(std::fabs(c->bvh.root_min[k]) < 1e30f) || !(std::fabs(c->bvh.root_max[k]) < 1e30f)) c->ts.tame = 0;
 
     // ---- shading tables: per-triangle attribute blocks, 3 x (normal uv tangent binormal)
     {
@@ -445,6 +517,7 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     if ((r = dev_upload(c, &c->d_q0, q0.data(), q0.size()))) return r;
     if ((r = dev_alloc(c, &c->d_q[0], n))) return r;
     if ((r = dev_alloc(c, &c->d_q[1], n))) return r;
+    if ((r = dev_alloc(c, &c->d_q[2], n))) return r;
     if ((r = dev_alloc(c, &c->pb.rays, 6 * n))) return r;
     if ((r = dev_alloc(c, &c->pb.hit_t, n))) return r;
     if ((r = dev_alloc(c, &c->pb.hit_id0, n))) return r;
@@ -453,7 +526,9 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     if ((r = dev_alloc(c, &c->pb.hit_v, n))) return r;
     if ((r = dev_alloc(c, &c->pb.beta, 3 * n))) return r;
     if ((r = dev_alloc(c, &c->pb.L, 3 * n))) return r;
-    if ((r = dev_alloc(c, &c->pb.vpos, 3 * n))) return r;
+    if ((r = dev_alloc(c, &c->vpos[0], 3 * n))) return r;
+    if ((r = dev_alloc(c, &c->vpos[1], 3 * n))) return r;
+    c->pb.vpos = c->vpos[0];
     if ((r = dev_alloc(c, &c->pb.status, n))) return r;
     if ((r = dev_alloc(c, &c->pb.film, n))) return r;
     HIP_TRY(c, hipMemset(c->pb.film, 0, (n ? n : 1) * sizeof(float4)));
@@ -462,20 +537,33 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     c->pb.n = (uint32_t)n;
 
     const int D = pr->max_depth, L = c->n_lights;
-    c->n_counts = (uint32_t)(D + 1 + D * L);
+    c->n_counts = (uint32_t)(D + 1 + D);
+    c->n_pass_work = (uint32_t)(2 * D);
+    if ((r = dev_alloc(c, &c->d_pass_work, c->n_pass_work))) return r;
+    if ((r = dev_alloc(c, &c->d_pass_deferred, n))) return r;
     std::vector<uint32_t> init(c->n_counts, 0u);
     init[0] = c->n_valid;
     if ((r = dev_upload(c, &c->d_counts_init, init.data(), init.size()))) return r;
     if ((r = dev_alloc(c, &c->d_counts, c->n_counts))) return r;
-    c->h_sq.resize(L);
-    for (int l = 0; l < L; ++l) {
-        ShadowQueue& q = c->h_sq[l];
-        q.cap = (uint32_t)n;
-        if ((r = dev_alloc(c, &q.slot, n))) return r;
-        if ((r = dev_alloc(c, &q.dir, 3 * n))) return r;
-        if ((r = dev_alloc(c, &q.contrib, 6 * n))) return r;
+    {
+        const size_t cap = (size_t)(L > 0 ? L : 1) * n;
+        if (cap >= 0xFFFFFFFFull) {
+            c->err = "lights x pixels exceeds the shadow queue limit";
+            return RT_ERR_LIMIT;
+        }
+        for (int p = 0; p < 2; ++p) {
+            ShadowQueue& q = c->sq[p];
+            q.cap = (uint32_t)cap;
+            if ((r = dev_alloc(c, &q.slot, cap))) return r;
+            if ((r = dev_alloc(c, &q.light, cap))) return r;
+            if ((r = dev_alloc(c, &q.dir, 3 * cap))) return r;
+            if ((r = dev_alloc(c, &q.contrib, 6 * cap))) return r;
+            if ((r = dev_alloc(c, &q.state, cap))) return r;
+        }
+        // the exact follow-up launch of k_shadow can defer up to every entry
+        if ((r = dev_alloc(c, &c->d_pass_deferred_b, cap))) return r;
     }
-    if ((r = dev_upload(c, &c->d_sq, c->h_sq.data(), c->h_sq.size()))) return r;
+    if ((r = dev_alloc(c, &c->d_work, 1))) return r;
     if ((r = dev_alloc(c, &c->d_raystats, 2))) return r;
     HIP_TRY(c, hipMemset(c->d_raystats, 0, 2 * sizeof(unsigned long long)));
     HIP_TRY(c, hipDeviceSynchronize());
@@ -698,7 +786,7 @@ int rt_lbvh_host(const float* pos, uint32_t pos_stride, const uint32_t* indices,
     if (!pos || !indices || !tri_model || n_indices < 3 || n_indices % 3 || !boxes || !left || !right || !tri || !model || !leaf)
         return RT_ERR_ARG;
     LbvhResult res;
-    build_lbvh(pos, pos_stride ? pos_stride : 12, indices, n_indices, tri_model, res);
+    build_lbvh(pos, pos_stride ? pos_stride : 12, indices, n_indices, tri_model, res, 0);
     if (max_depth) *max_depth = res.max_depth;
     for (size_t i = 0; i < res.ref.size(); ++i) {
         for (int k = 0; k < 3; ++k) { boxes[6 * i + k] = res.ref[i].bmin[k]; boxes[6 * i + 3 + k] = res.ref[i].bmax[k]; }

@@ -313,27 +313,31 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(PathBuffers pb, CameraK c
     pb.rays[3 * n + s] = d.x; pb.rays[4 * n + s] = d.y; pb.rays[5 * n + s] = d.z;
 }
 
-// Shadow-ray queue of one light: slot, direction and the two contributions
-// the reference adds, one after the other, once the ray is found unoccluded
-// (src/cpu/PathTracer.cpp:107 or :109, then :123).  Planes of `cap` entries.
+// Shadow rays of one bounce, all lights in one queue: entry k names the path
+// slot and the light, and carries the ray direction (the origin is the
+// path's shaded vertex).  What the ray would add is kept per (light, slot):
+// the two contributions the reference adds one after the other once the ray
+// is found unoccluded (src/cpu/PathTracer.cpp:107 or :109, then :123), and a
+// state byte: 0 no ray, 1 ray queued, 2 ray found unoccluded.
 struct ShadowQueue {
-    uint32_t* slot;
-    float* dir;      // 3 planes
-    float* contrib;  // 6 planes: first term rgb, second term rgb
-    uint32_t cap;
+    uint32_t* slot;    // [cap]
+    uint32_t* light;   // [cap]
+    float* dir;        // 3 planes of cap
+    float* contrib;    // 6 planes of cap, indexed light * n_slots + slot
+    uint8_t* state;    // [cap], indexed light * n_slots + slot
+    uint32_t cap;      // n_lights * n_slots
 };
 
 // One bounce of src/cpu/PathTracer.cpp:56-65 (d = 0 miss) and :95-144 for
 // every path in the queue: BVH::postIntersect (src/scene/BVH.cpp:172-187),
 // Material::computeBSDF (src/scene/Material.cpp:214-225), per-light sampling
 // with the contributions the reference would add once the shadow ray is
-// found unoccluded, then the BSDF bounce.  sq[l] / sq_counts[l] belong to
-// light l of this bounce.
+// found unoccluded, then the BSDF bounce.
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene sc, int depth, int max_depth, uint64_t seed_mixed,
                                                     uint32_t pass, const uint32_t* __restrict__ queue,
                                                     const uint32_t* __restrict__ d_count, uint32_t* __restrict__ next_queue,
-                                                    uint32_t* __restrict__ next_count, const ShadowQueue* __restrict__ sq,
-                                                    uint32_t* __restrict__ sq_counts) {
+                                                    uint32_t* __restrict__ next_count, ShadowQueue sq,
+                                                    uint32_t* __restrict__ sq_count) {
     const uint32_t count = *d_count;
     const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t gsize = gridDim.x * RT_BLOCK;
@@ -444,14 +448,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
                     }
                 }
             }
-            uint32_t k = wave_append(emit, sq_counts + l);
+            // a shadow ray that could only add exact zeros changes nothing whether
+            // or not it is occluded (L + 0 == L), so it is not traced
+            emit = emit && !(is_zero3(C) && is_zero3(C2));
+            uint32_t k = wave_append(emit, sq_count);
+            if (valid) sq.state[(size_t)l * n + s] = emit ? 1 : 0;
             if (emit) {
-                const ShadowQueue q = sq[l];
-                size_t cap = q.cap;
-                q.slot[k] = s;
-                q.dir[k] = in.x; q.dir[cap + k] = in.y; q.dir[2 * cap + k] = in.z;
-                q.contrib[k] = C.x; q.contrib[cap + k] = C.y; q.contrib[2 * cap + k] = C.z;
-                q.contrib[3 * cap + k] = C2.x; q.contrib[4 * cap + k] = C2.y; q.contrib[5 * cap + k] = C2.z;
+                const size_t cap = sq.cap, e = (size_t)l * n + s;
+                sq.slot[k] = s;
+                sq.light[k] = (uint32_t)l;
+                sq.dir[k] = in.x; sq.dir[cap + k] = in.y; sq.dir[2 * cap + k] = in.z;
+                sq.contrib[e] = C.x; sq.contrib[cap + e] = C.y; sq.contrib[2 * cap + e] = C.z;
+                sq.contrib[3 * cap + e] = C2.x; sq.contrib[4 * cap + e] = C2.y; sq.contrib[5 * cap + e] = C2.z;
             }
         }
 
@@ -478,30 +486,51 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
     }
 }
 
-// Resolves one light's shadow queue: BVH::occluded from the shaded vertex
-// (src/cpu/PathTracer.cpp:101-102), then the adds of :107/:109 and :123.
-// Each path has at most one entry per light, so the adds do not race, and
-// the per-light launches run in light order like the reference's loop.
-__global__ __launch_bounds__(RT_BLOCK) void k_shadow(TraceScene ts, PathBuffers pb, ShadowQueue q, const uint32_t* __restrict__ d_count,
+// Traces the bounce's shadow rays, every light in one launch:
+// BVH::occluded from the shaded vertex (src/cpu/PathTracer.cpp:101-102).  An
+// unoccluded ray only marks its (light, slot) state; k_accumulate then adds
+// the contributions in the reference's order.
+template <bool EXACT>
+__global__ __launch_bounds__(RT_TBLOCK) void k_shadow(TraceScene ts, PathBuffers pb, ShadowQueue q, const uint32_t* __restrict__ d_count,
+                                                     TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
                                                      unsigned long long* __restrict__ ray_counter) {
-    __shared__ int32_t s_stack[RT_STACK_LDS * RT_BLOCK];
-    const uint32_t count = *d_count;
-    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t gsize = gridDim.x * RT_BLOCK;
+    __shared__ int32_t s_stack[RT_STACK_LDS * RT_TBLOCK];
+    __shared__ __attribute__((aligned(16))) char s_top[RT_TOP_BYTES];
+    const TopTree top = stage_top_tree(ts.nodes, ts.n_nodes, s_top);
+    const uint32_t count = EXACT ? work->n_deferred : *d_count;
     const size_t n = pb.n, cap = q.cap;
-    if (gtid == 0) atomicAdd(ray_counter, (unsigned long long)count);
-    for (uint32_t i = gtid; i < count; i += gsize) {
-        uint32_t s = q.slot[i];
-        f3 org = mk3(pb.vpos[s], pb.vpos[n + s], pb.vpos[2 * n + s]);
-        f3 dir = mk3(q.dir[i], q.dir[cap + i], q.dir[2 * cap + i]);
-        HitRec h = trace_ray<true>(ts, org, dir, s_stack, gtid);
-        if (h.id1 < 0) {
-            f3 Lp = mk3(pb.L[s], pb.L[n + s], pb.L[2 * n + s]);
-            Lp = Lp + mk3(q.contrib[i], q.contrib[cap + i], q.contrib[2 * cap + i]);
-            f3 C2 = mk3(q.contrib[3 * cap + i], q.contrib[4 * cap + i], q.contrib[5 * cap + i]);
+    if (!EXACT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)count);
+    trace_persistent<true, EXACT>(
+        ts, count, work, deferred, s_stack, top,
+        [&](uint32_t i, f3& org, f3& dir) {
+            uint32_t s = q.slot[i];
+            org = mk3(pb.vpos[s], pb.vpos[n + s], pb.vpos[2 * n + s]);
+            dir = mk3(q.dir[i], q.dir[cap + i], q.dir[2 * cap + i]);
+        },
+        [&](uint32_t i, const HitRec& h) {
+            if (h.id1 < 0) q.state[(size_t)q.light[i] * n + q.slot[i]] = 2;
+        });
+}
+
+// The adds of src/cpu/PathTracer.cpp:107/:109 and :123 for every path of the
+// bounce, light by light in the reference's loop order.
+__global__ __launch_bounds__(RT_BLOCK) void k_accumulate(PathBuffers pb, ShadowQueue q, int n_lights, const uint32_t* __restrict__ queue,
+                                                         const uint32_t* __restrict__ d_count) {
+    const uint32_t count = *d_count;
+    const size_t n = pb.n, cap = q.cap;
+    for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < count; i += gridDim.x * RT_BLOCK) {
+        const uint32_t s = queue[i];
+        f3 Lp = mk3(pb.L[s], pb.L[n + s], pb.L[2 * n + s]);
+        bool any = false;
+        for (int l = 0; l < n_lights; ++l) {
+            const size_t e = (size_t)l * n + s;
+            if (q.state[e] != 2) continue;
+            any = true;
+            Lp = Lp + mk3(q.contrib[e], q.contrib[cap + e], q.contrib[2 * cap + e]);
+            f3 C2 = mk3(q.contrib[3 * cap + e], q.contrib[4 * cap + e], q.contrib[5 * cap + e]);
             if (!is_zero3(C2)) Lp = Lp + C2;
-            pb.L[s] = Lp.x; pb.L[n + s] = Lp.y; pb.L[2 * n + s] = Lp.z;
         }
+        if (any) { pb.L[s] = Lp.x; pb.L[n + s] = Lp.y; pb.L[2 * n + s] = Lp.z; }
     }
 }
 

@@ -8,26 +8,61 @@
 // the second recursive call at src/scene/BVH.cpp:165-166, so every cull
 // decision and therefore every hit id equals the scalar path's.
 //
-// Stack: the first RT_STACK_LDS entries of each lane live in LDS, laid out
-// [level][thread] so that a wave's access to any mix of levels is
-// bank-conflict-free; deeper entries spill to a global buffer indexed by the
-// launch-wide thread id (the grid is persistent, so that buffer is small).
+// Scheduling (free, because each lane's own sequence of steps is what fixes
+// the result): waves are persistent and pull rays in chunks from a global
+// counter; every loop iteration the wave votes and runs ONE of three bodies
+// for the lanes that want it -- refill idle lanes with new rays, one
+// inner-node step, or one triangle test -- so the inner and leaf bodies never
+// both issue for one iteration and lanes whose ray has finished do not idle
+// until the slowest ray of the wave is done.
+//
+// LDS (per 512-thread workgroup: 28 KB of nodes + 24 KB of stack, three
+// workgroups per CU):
+//  * the top of the tree: the first RT_TOP_NODES inner nodes in breadth-first
+//    order, as four SoA planes.  About half of all node visits land there;
+//    they were mostly L1 hits before, so the measured gain is small (a few
+//    percent on incoherent rays): what bounds the kernel is the rate at
+//    which the deep, cache-missing visits pull new lines from L2;
+//  * the traversal stack: the first RT_STACK_LDS entries of each lane, laid
+//    out [level][thread] so a wave's access to any mix of levels is
+//    bank-conflict-free; deeper entries spill to a global buffer indexed by
+//    the launch-wide thread id (the grid is persistent, so it is small).
 #pragma once
 #include "device_math.h"
 
 namespace rt {
 
-#define RT_BLOCK 256
-#define RT_STACK_LDS 24
+#define RT_BLOCK 256        // shading kernels
+#ifndef RT_TBLOCK
+#define RT_TBLOCK 512       // traversal kernels: 3 workgroups (24 waves) per CU
+#endif
+#ifndef RT_STACK_LDS
+#define RT_STACK_LDS 12
+#endif
+#ifndef RT_TOP_NODES
+#define RT_TOP_NODES 512    // inner nodes kept in LDS (56 B each): levels 0-8 of a full tree
+#endif
+// vote thresholds (lanes of 64)
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 20   // refill when at least this many lanes are idle
+#endif
+#ifndef RT_LEAF_MIN
+#define RT_LEAF_MIN 12     // run a triangle step when at least this many lanes wait on a leaf
+#endif
+#ifndef RT_CHUNK
+#define RT_CHUNK 128       // items a wave takes from the shared counter at a time
+#endif
 
 struct TraceScene {
     const float4* nodes;   // 4 float4 per inner node (DevNode)
     const float4* tris;    // 3 float4 per triangle (DevTri)
     int32_t root_link;
+    int32_t n_nodes;       // inner nodes
     float rmin[3], rmax[3];
     int32_t* ovf;          // overflow stack, [level - RT_STACK_LDS][grid thread]
     uint32_t ovf_stride;   // threads in the persistent grid
     uint32_t ovf_levels;
+    int32_t tame;          // every box coordinate is finite and below 1e30 in magnitude
 };
 
 // src/scene/Ray.cpp:17-34
@@ -41,6 +76,42 @@ RT_DEV bool slab_test(f3 org, f3 inv, float bx0, float by0, float bz0, float bx1
     dist = tmin;
     return (tmin <= tmax) && (tmax > 0.0f);
 }
+
+// The same test with hardware min/max.  v_min_f32/v_max_f32 pick the same
+// operand as glm's (y<x)?y:x / (x<y)?y:x whenever neither input is a NaN
+// (they may differ in the sign of a zero result, which no comparison below
+// can see), so this form is used only for rays whose origin and inverse
+// direction are finite and moderate: then inv*(b-org) is never inf*0.
+RT_DEV bool slab_test_fast(f3 org, f3 inv, float bx0, float by0, float bz0, float bx1, float by1, float bz1, float& dist) {
+    float lox = inv.x * (bx0 - org.x), loy = inv.y * (by0 - org.y), loz = inv.z * (bz0 - org.z);
+    float hix = inv.x * (bx1 - org.x), hiy = inv.y * (by1 - org.y), hiz = inv.z * (bz1 - org.z);
+    float tmin = fmaxf(fminf(lox, hix), fmaxf(fminf(loy, hiy), fminf(loz, hiz)));
+    float tmax = fminf(fmaxf(lox, hix), fminf(fmaxf(loy, hiy), fmaxf(loz, hiz)));
+    dist = tmin;
+    return (tmin <= tmax) && (tmax > 0.0f);
+}
+
+// Per-lane traversal stack: levels below RT_STACK_LDS in LDS, the rest in
+// the global overflow buffer.
+struct LaneStack {
+    int32_t* lds;      // &stack[tid]
+    int32_t* ovf;      // &ovf[gtid]
+    uint32_t ovf_stride;
+    RT_DEV void push(int sp, int32_t x) const {
+        if (sp < RT_STACK_LDS) lds[sp * RT_TBLOCK] = x;
+        else ovf[(size_t)(sp - RT_STACK_LDS) * ovf_stride] = x;
+    }
+    RT_DEV int32_t pop(int sp) const {
+        int32_t x;
+        if (sp < RT_STACK_LDS) {
+            x = lds[sp * RT_TBLOCK];
+            asm volatile("" : "+v"(x));  // keeps this a ds_read (see the node fetch)
+        } else {
+            x = ovf[(size_t)(sp - RT_STACK_LDS) * ovf_stride];
+        }
+        return x;
+    }
+};
 
 // src/scene/Ray.cpp:36-67
 RT_DEV bool tri_test(f3 org, f3 dir, f3 v0, f3 v1, f3 v2, float& dist, float& u, float& v) {
@@ -74,100 +145,283 @@ RT_DEV f3 make_invdir(f3 d) {
     return inv;
 }
 
-template <bool ANY_HIT>
-RT_DEV HitRec trace_ray(const TraceScene& sc, f3 org, f3 dir, int32_t* lds_stack, uint32_t gtid) {
-    HitRec h;
-    h.t = __builtin_inff();
-    h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
-    f3 inv = make_invdir(dir);
-    float rd;
-    if (!slab_test(org, inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2], rd)) return h;
+RT_DEV bool moderate(float x) { return fabsf(x) < 1e30f; }  // false for NaN and inf too
 
-    int32_t cur = sc.root_link;
-    int sp = 0;
+// The LDS-resident top of the tree, SoA: node k = (b0[k], b1[k], b2[k]) child
+// boxes (48 B, DevNode's first three float4) and lk[k] = (left, right).
+struct TopTree {
+    const float4* b0;
+    const float4* b1;
+    const float4* b2;
+    const int2* lk;
+    int32_t n;   // nodes resident (a prefix of the node array)
+};
+
+#define RT_TOP_BYTES (RT_TOP_NODES * 56)
+
+// Copies the first min(n_nodes, RT_TOP_NODES) nodes into LDS; every thread
+// of the workgroup calls it, followed by a barrier.
+RT_DEV TopTree stage_top_tree(const float4* nodes, int32_t n_nodes, char* lds) {
+    float4* b0 = reinterpret_cast<float4*>(lds);
+    float4* b1 = b0 + RT_TOP_NODES;
+    float4* b2 = b1 + RT_TOP_NODES;
+    int2* lk = reinterpret_cast<int2*>(b2 + RT_TOP_NODES);
+    const int32_t n = n_nodes < RT_TOP_NODES ? n_nodes : RT_TOP_NODES;
+    for (int32_t k = threadIdx.x; k < n; k += RT_TBLOCK) {
+        const float4* np = nodes + (size_t)k * 4;
+        b0[k] = np[0]; b1[k] = np[1]; b2[k] = np[2];
+        float4 d = np[3];
+        lk[k] = make_int2(__float_as_int(d.x), __float_as_int(d.y));
+    }
+    __syncthreads();
+    TopTree t;
+    t.b0 = b0; t.b1 = b1; t.b2 = b2; t.lk = lk; t.n = n;
+    return t;
+}
+
+// Work counters of one traversal launch (zeroed before the launch).
+struct TraceWork {
+    uint32_t next;         // next unclaimed item of the main launch
+    uint32_t n_deferred;   // items handed to the exact launch
+    uint32_t next_exact;   // next unclaimed entry of the deferred list
+    uint32_t pad;
+};
+
+// Persistent traversal of `count` work items.  `load(i, org, dir)` fetches
+// work item i; `done(i, hit)` consumes its result (hit.id1 < 0 = nothing
+// hit).
+//
+// EXACT = false is the main launch: box tests use hardware min/max, and a
+// ray whose origin or inverse direction is not finite and moderate (where
+// inf*0 could make a NaN and min/max would no longer equal the reference's
+// selects) is not traced but appended to `deferred`.  EXACT = true is the
+// follow-up launch over that list (count = work->n_deferred) with the
+// select-based box test; it is almost always empty.
+template <bool ANY_HIT, bool EXACT, typename Load, typename Done>
+RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* work, uint32_t* deferred, int32_t* lds_stack,
+                             const TopTree& top, Load load, Done done) {
     const uint32_t tid = threadIdx.x;
+    const uint32_t gtid = blockIdx.x * RT_TBLOCK + tid;
+    const uint32_t lane = tid & 63u;
+    const float inf = __builtin_inff();
+    uint32_t* next = EXACT ? &work->next_exact : &work->next;
+    LaneStack stk;
+    stk.lds = lds_stack + tid;
+    stk.ovf = sc.ovf + gtid;
+    stk.ovf_stride = sc.ovf_stride;
+
+    // Items a wave takes from the shared counter at a time: RT_CHUNK when
+    // there is plenty of work (few atomics, contiguous rays per wave), fewer
+    // when the launch is small, so that a short queue spreads over many waves
+    // instead of running as long serial chains on a few of them.
+    const uint32_t per_wave = count / (gridDim.x * (RT_TBLOCK / 64));
+    const uint32_t chunk = per_wave >= RT_CHUNK ? RT_CHUNK : (per_wave >= 64 ? 64 : (per_wave >= 32 ? 32 : 16));
+
+    bool have = false;         // this lane holds a ray
+    bool exhausted = false;    // wave-uniform: the work counter ran past count
+    uint32_t c_next = 0, c_end = 0;  // wave-uniform: the chunk of items this wave is handing out
+    uint32_t item = 0;
+    int32_t cur = 0;
+    int sp = 0;
+    f3 org = mk3(0.f, 0.f, 0.f), dir = mk3(0.f, 0.f, 1.f), inv = mk3(0.f, 0.f, 1.f);
+    HitRec h;
+    h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
+
     for (;;) {
-        if (cur >= 0) {
-            const float4* np = sc.nodes + (size_t)cur * 4;
-            float4 a = np[0], b = np[1], c = np[2], d = np[3];
-            float ld, rdist;
-            bool ls = slab_test(org, inv, a.x, a.y, a.z, a.w, b.x, b.y, ld);
-            bool rs = slab_test(org, inv, b.z, b.w, c.x, c.y, c.z, c.w, rdist);
-            ls = ls && (ld < h.t);
-            rs = rs && (rdist < h.t);
-            int32_t left = __float_as_int(d.x), right = __float_as_int(d.y);
-            if (ls && rs) {
-                int32_t nearL = left, farL = right;
-                if (rdist < ld) { nearL = right; farL = left; }
-                if (sp < RT_STACK_LDS) lds_stack[sp * RT_BLOCK + tid] = farL;
-                else sc.ovf[(size_t)(sp - RT_STACK_LDS) * sc.ovf_stride + gtid] = farL;
-                ++sp;
-                cur = nearL;
-                continue;
-            } else if (ls) {
-                cur = left;
-                continue;
-            } else if (rs) {
-                cur = right;
-                continue;
+        const unsigned long long m_idle = __ballot(!have);
+        const int n_idle = __popcll(m_idle);
+        if (n_idle >= RT_REFILL_MIN && (c_next < c_end || !exhausted)) {
+            // ---- refill idle lanes from the wave's chunk; one atomic per
+            // chunk keeps the shared counter far from saturation and keeps a
+            // wave inside one contiguous run of rays
+            if (c_next >= c_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(next, chunk);
+                base = __shfl(base, 0);
+                if (base >= count) { exhausted = true; continue; }
+                c_next = base;
+                c_end = (count - base < chunk) ? count : base + chunk;
+            }
+            const uint32_t avail = c_end - c_next;
+            const uint32_t k = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
+            if (!have) {
+                uint32_t r = __popcll(m_idle & ((1ull << lane) - 1ull));
+                if (r < k) {
+                    uint32_t i = c_next + r;
+                    if (EXACT) i = deferred[i];
+                    item = i;
+                    load(i, org, dir);
+                    inv = make_invdir(dir);
+                    h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
+                    float rd;
+                    // root box test of src/scene/BVH.cpp:51-53
+                    if (slab_test(org, inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2], rd)) {
+                        const bool tame = EXACT || (sc.tame && moderate(org.x) && moderate(org.y) && moderate(org.z) &&
+                                                    moderate(inv.x) && moderate(inv.y) && moderate(inv.z));
+                        if (tame) {
+                            have = true;
+                            cur = sc.root_link;
+                            sp = 0;
+                        } else {
+                            deferred[atomicAdd(&work->n_deferred, 1u)] = i;
+                        }
+                    } else {
+                        done(i, h);
+                    }
+                }
+            }
+            c_next += k;
+            continue;
+        }
+        if (n_idle == 64) break;  // nothing in flight and nothing left to fetch
+
+        const bool want_leaf = have && cur < 0;
+        const int n_leaf = __popcll(__ballot(want_leaf));
+        const int n_inner = 64 - n_idle - n_leaf;
+        if (n_inner > 0 && n_leaf < RT_LEAF_MIN) {
+            // ---- one inner-node step for the lanes standing on an inner node
+            if (have && cur >= 0) {
+                float4 a, b, c;
+                int32_t left, right;
+                if (cur < top.n) {
+                    a = top.b0[cur]; b = top.b1[cur]; c = top.b2[cur];
+                    int2 l2 = top.lk[cur];
+                    left = l2.x; right = l2.y;
+                    // pins these as LDS reads: without it the compiler folds the two
+                    // branches into flat-address loads of a selected pointer
+                    asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(left));
+                } else {
+                    const float4* np = sc.nodes + (size_t)cur * 4;
+                    a = np[0]; b = np[1]; c = np[2];
+                    float4 d = np[3];
+                    left = __float_as_int(d.x); right = __float_as_int(d.y);
+                }
+                float ld, rdist;
+                bool ls, rs;
+                if (EXACT) {
+                    ls = slab_test(org, inv, a.x, a.y, a.z, a.w, b.x, b.y, ld);
+                    rs = slab_test(org, inv, b.z, b.w, c.x, c.y, c.z, c.w, rdist);
+                } else {
+                    ls = slab_test_fast(org, inv, a.x, a.y, a.z, a.w, b.x, b.y, ld);
+                    rs = slab_test_fast(org, inv, b.z, b.w, c.x, c.y, c.z, c.w, rdist);
+                }
+                ls = ls && (ld < h.t);
+                rs = rs && (rdist < h.t);
+                if (ls && rs) {
+                    const bool swap = rdist < ld;
+                    stk.push(sp, swap ? left : right);
+                    ++sp;
+                    cur = swap ? right : left;
+                } else if (ls || rs) {
+                    cur = ls ? left : right;
+                } else if (sp > 0) {
+                    --sp;
+                    cur = stk.pop(sp);
+                } else {
+                    have = false;
+                    done(item, h);
+                }
             }
         } else {
-            const float4* tp = sc.tris + (size_t)(~cur) * 3;
-            float4 a = tp[0], b = tp[1], c = tp[2];
-            float t, u, v;
-            if (tri_test(org, dir, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v)) {
-                if (ANY_HIT) {
-                    if (t > 0.0001f) { h.t = t; h.u = u; h.v = v; h.id1 = __float_as_int(c.y); h.id0 = __float_as_int(c.z); return h; }
-                } else if (t > 0.0001f && t < h.t) {
-                    h.t = t; h.u = u; h.v = v;
-                    h.id1 = __float_as_int(c.y);
-                    h.id0 = __float_as_int(c.z);
+            // ---- one triangle test for the lanes standing on a leaf
+            if (want_leaf) {
+                const float4* tp = sc.tris + (size_t)(~cur) * 3;
+                float4 a = tp[0], b = tp[1], c = tp[2];
+                float t, u, v;
+                bool finished = false;
+                if (tri_test(org, dir, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v)) {
+                    // src/scene/BVH.cpp:139 (closest) / :93 (any)
+                    if (t > 0.0001f && (ANY_HIT || t < h.t)) {
+                        h.t = t; h.u = u; h.v = v;
+                        h.id1 = __float_as_int(c.y);
+                        h.id0 = __float_as_int(c.z);
+                        if (ANY_HIT) finished = true;
+                    }
+                }
+                if (!finished && sp > 0) {
+                    --sp;
+                    cur = stk.pop(sp);
+                } else {
+                    have = false;
+                    done(item, h);
                 }
             }
         }
-        if (sp == 0) break;
-        --sp;
-        cur = (sp < RT_STACK_LDS) ? lds_stack[sp * RT_BLOCK + tid]
-                                  : sc.ovf[(size_t)(sp - RT_STACK_LDS) * sc.ovf_stride + gtid];
     }
-    if (ANY_HIT) h.t = __builtin_inff();
-    return h;
 }
 
-// Closest hit over a ray set.  rays: 6 planes of `stride` floats.  When
-// `queue` is non-null entry i names the ray slot, otherwise slot = i.  The
-// number of entries is *d_count when d_count is non-null, else n.
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_closest(TraceScene sc, const float* __restrict__ rays, uint32_t stride,
-                                                            const uint32_t* __restrict__ queue, const uint32_t* __restrict__ d_count,
-                                                            uint32_t n, float* __restrict__ o_t, int32_t* __restrict__ o_id0,
+// Closest hit over a ray set (the batch form of BVH::intersect).  rays: 6
+// planes of `stride` floats; outputs indexed like the rays.
+template <bool EXACT>
+__global__ __launch_bounds__(RT_TBLOCK) void k_trace_closest(TraceScene sc, const float* __restrict__ rays, uint32_t stride, uint32_t n,
+                                                            TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
+                                                            float* __restrict__ o_t, int32_t* __restrict__ o_id0,
                                                             int32_t* __restrict__ o_id1, float* __restrict__ o_u, float* __restrict__ o_v,
                                                             unsigned long long* __restrict__ ray_counter) {
-    __shared__ int32_t s_stack[RT_STACK_LDS * RT_BLOCK];
-    const uint32_t count = d_count ? *d_count : n;
-    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t gsize = gridDim.x * RT_BLOCK;
-    if (ray_counter && gtid == 0) atomicAdd(ray_counter, (unsigned long long)count);
-    for (uint32_t i = gtid; i < count; i += gsize) {
-        uint32_t s = queue ? queue[i] : i;
-        f3 org = mk3(rays[s], rays[stride + s], rays[2 * (size_t)stride + s]);
-        f3 dir = mk3(rays[3 * (size_t)stride + s], rays[4 * (size_t)stride + s], rays[5 * (size_t)stride + s]);
-        HitRec h = trace_ray<false>(sc, org, dir, s_stack, gtid);
-        o_t[s] = h.t; o_id0[s] = h.id0; o_id1[s] = h.id1; o_u[s] = h.u; o_v[s] = h.v;
-    }
+    __shared__ int32_t s_stack[RT_STACK_LDS * RT_TBLOCK];
+    __shared__ __attribute__((aligned(16))) char s_top[RT_TOP_BYTES];
+    const TopTree top = stage_top_tree(sc.nodes, sc.n_nodes, s_top);
+    if (!EXACT && ray_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)n);
+    const uint32_t count = EXACT ? work->n_deferred : n;
+    const size_t st = stride;
+    trace_persistent<false, EXACT>(
+        sc, count, work, deferred, s_stack, top,
+        [&](uint32_t i, f3& org, f3& dir) {
+            org = mk3(rays[i], rays[st + i], rays[2 * st + i]);
+            dir = mk3(rays[3 * st + i], rays[4 * st + i], rays[5 * st + i]);
+        },
+        [&](uint32_t i, const HitRec& h) {
+            o_t[i] = h.t; o_id0[i] = h.id0; o_id1[i] = h.id1; o_u[i] = h.u; o_v[i] = h.v;
+        });
 }
 
-// Any hit over a ray set; status[i] = 1 when something is hit.
-__global__ __launch_bounds__(RT_BLOCK) void k_trace_occluded(TraceScene sc, const float* __restrict__ rays, uint32_t stride, uint32_t n,
+// The same traversal driven by a queue of path slots (one bounce of the
+// wavefront tracer): entry i of `queue` names the slot whose ray is traced
+// and whose hit record is written.
+template <bool EXACT>
+__global__ __launch_bounds__(RT_TBLOCK) void k_extend(TraceScene sc, const float* __restrict__ rays, uint32_t stride,
+                                                     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ d_count,
+                                                     TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
+                                                     float* __restrict__ o_t, int32_t* __restrict__ o_id0, int32_t* __restrict__ o_id1,
+                                                     float* __restrict__ o_u, float* __restrict__ o_v,
+                                                     unsigned long long* __restrict__ ray_counter) {
+    __shared__ int32_t s_stack[RT_STACK_LDS * RT_TBLOCK];
+    __shared__ __attribute__((aligned(16))) char s_top[RT_TOP_BYTES];
+    const TopTree top = stage_top_tree(sc.nodes, sc.n_nodes, s_top);
+    const uint32_t count = EXACT ? work->n_deferred : *d_count;
+    if (!EXACT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)count);
+    const size_t st = stride;
+    trace_persistent<false, EXACT>(
+        sc, count, work, deferred, s_stack, top,
+        [&](uint32_t i, f3& org, f3& dir) {
+            uint32_t s = queue[i];
+            org = mk3(rays[s], rays[st + s], rays[2 * st + s]);
+            dir = mk3(rays[3 * st + s], rays[4 * st + s], rays[5 * st + s]);
+        },
+        [&](uint32_t i, const HitRec& h) {
+            uint32_t s = queue[i];
+            o_t[s] = h.t; o_id0[s] = h.id0; o_id1[s] = h.id1; o_u[s] = h.u; o_v[s] = h.v;
+        });
+}
+
+// Any hit over a ray set (the batch form of BVH::occluded); status[i] = 1
+// when something is hit.
+template <bool EXACT>
+__global__ __launch_bounds__(RT_TBLOCK) void k_trace_occluded(TraceScene sc, const float* __restrict__ rays, uint32_t stride, uint32_t n,
+                                                             TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
                                                              int32_t* __restrict__ status) {
-    __shared__ int32_t s_stack[RT_STACK_LDS * RT_BLOCK];
-    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
-    const uint32_t gsize = gridDim.x * RT_BLOCK;
-    for (uint32_t i = gtid; i < n; i += gsize) {
-        f3 org = mk3(rays[i], rays[stride + i], rays[2 * (size_t)stride + i]);
-        f3 dir = mk3(rays[3 * (size_t)stride + i], rays[4 * (size_t)stride + i], rays[5 * (size_t)stride + i]);
-        HitRec h = trace_ray<true>(sc, org, dir, s_stack, gtid);
-        status[i] = (h.id1 >= 0) ? 1 : 0;
-    }
+    __shared__ int32_t s_stack[RT_STACK_LDS * RT_TBLOCK];
+    __shared__ __attribute__((aligned(16))) char s_top[RT_TOP_BYTES];
+    const TopTree top = stage_top_tree(sc.nodes, sc.n_nodes, s_top);
+    const uint32_t count = EXACT ? work->n_deferred : n;
+    const size_t st = stride;
+    trace_persistent<true, EXACT>(
+        sc, count, work, deferred, s_stack, top,
+        [&](uint32_t i, f3& org, f3& dir) {
+            org = mk3(rays[i], rays[st + i], rays[2 * st + i]);
+            dir = mk3(rays[3 * st + i], rays[4 * st + i], rays[5 * st + i]);
+        },
+        [&](uint32_t i, const HitRec& h) { status[i] = (h.id1 >= 0) ? 1 : 0; });
 }
 
 }  // namespace rt

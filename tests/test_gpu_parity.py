@@ -110,3 +110,73 @@ def test_render_atrium_matches_oracle(atrium_small):
     ref, _ = orc.render(atrium_small.camera, W, H, 4, 5, 2)
     _film_check(film, ref, 1e-3, frac_tol=1e-2)
     ctx.close()
+
+
+def test_untame_rays_take_the_exact_path(atrium_small):
+    """Rays whose origin or inverse direction is not finite and moderate are
+    traced by the follow-up launch with the select-based box test; results
+    must still equal the oracle's bit for bit (NaN/inf semantics included)."""
+    ctx, orc = Context(atrium_small, 64, 64), OracleScene(atrium_small)
+    rays = scenes.incoherent_rays(atrium_small, 4096, seed=21).copy()
+    lo, hi = atrium_small.pos.min(0), atrium_small.pos.max(0)
+    tiny = np.float32(1e-42)  # denormal direction component: 1/d = inf
+    rays[3, 0::8] = tiny
+    rays[4, 1::8] = -tiny
+    rays[5, 2::8] = 0.0                      # exact zero: invdir forced to 0
+    rays[0, 3::16] = np.float32(lo[0])       # origin exactly on a box plane
+    rays[3, 3::16] = tiny                    # ... with an infinite invdir: inf * 0
+    rays[1, 4::64] = np.nan
+    rays[3, 5::64] = np.inf
+    rays[0, 6::64] = np.float32(3e38)
+    rays[2, 7::64] = -np.inf
+    t, id0, id1, u, v = ctx.trace_closest(rays)
+    rt, rid0, rid1, ru, rv = orc.intersect(rays)
+    assert np.array_equal(id1, rid1) and np.array_equal(id0, rid0)
+    assert np.array_equal(_bits(t), _bits(rt)) and np.array_equal(_bits(u), _bits(ru)) and np.array_equal(_bits(v), _bits(rv))
+    assert np.array_equal(ctx.trace_occluded(rays), orc.occluded(rays))
+    assert (id1 >= 0).sum() > 1000
+    ctx.close()
+
+
+def test_render_depth8_larger_film_matches_oracle(atrium_small):
+    """Deeper paths on a film large enough to keep both streams of a pass busy
+    (the shadow chain overlaps the next bounce's extend/shade)."""
+    W, H = 480, 270
+    ctx, orc = Context(atrium_small, W, H, max_depth=8, seed=11), OracleScene(atrium_small)
+    ctx.set_camera(atrium_small.camera)
+    ctx.render(3)
+    film = ctx.read_film()
+    ref, cnt = orc.render(atrium_small.camera, W, H, 8, 11, 3)
+    _film_check(film, ref, 1e-3, frac_tol=1e-2)
+    st = ctx.stats()
+    # the GPU skips the closest-hit ray of the last loop iteration and shadow
+    # rays that could only add zeros, so it traces no more rays than the oracle
+    assert 0 < st["closest_rays"] <= cnt["closest"] and 0 < st["shadow_rays"] <= cnt["shadow"]
+    ctx.close()
+
+
+def test_render_is_deterministic_at_full_size():
+    """Two renders of the 1080p Sponza-class workload must agree bit for bit
+    (any race between the two streams of a pass would show up here), and the
+    tile-sharded render of rank 0 of 2 must equal the same pixels of the
+    unsharded one."""
+    scene = scenes.sponza_class(env_size=(512, 256))
+    W, H = 1920, 1080
+    films = []
+    for _ in range(2):
+        ctx = Context(scene, W, H, max_depth=8, seed=2)
+        ctx.set_camera(scene.camera)
+        ctx.render(2)
+        films.append(ctx.read_film())
+        ctx.close()
+    assert np.array_equal(_bits(films[0]), _bits(films[1]))
+    assert np.isfinite(films[0]).all() and films[0][..., :3].max() > 0
+    ctx = Context(scene, W, H, max_depth=8, seed=2, rank=0, world=2)
+    ctx.set_camera(scene.camera)
+    ctx.render(2)
+    half = ctx.read_film()
+    ctx.close()
+    ty, tx = np.mgrid[0:H, 0:W]
+    mine = ((ty // 64) * (-(-W // 64)) + tx // 64) % 2 == 0
+    assert np.array_equal(_bits(half[mine]), _bits(films[0][mine]))
+    assert not half[~mine].any()
