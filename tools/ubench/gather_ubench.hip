@@ -82,6 +82,13 @@ void run(const char* name, const float4* d_nodes, uint32_t n_nodes, float* d_out
            visits / (ms * 1e-3) / 2.4e9 / num_cu);
 }
 
+// streaming calibration: every thread reads 16 B, grid-strided, whole table once
+__global__ __launch_bounds__(256) void k_stream(const float4* __restrict__ t, size_t n4, float* out) {
+    float acc = 0.f;
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { float4 a = t[i]; acc += a.x + a.w; }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 int main(int argc, char** argv) {
     uint32_t mb = argc > 1 ? atoi(argv[1]) : 16;
     uint32_t n_nodes = mb * 1024u * 1024u / 64;
@@ -93,6 +100,15 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_nodes, (size_t)n_nodes * 64)); CK(hipMalloc(&d_out, (size_t)blocks * 256 * 4));
     CK(hipMemcpy(d_nodes, h.data(), (size_t)n_nodes * 64, hipMemcpyHostToDevice));
     printf("table %u MB (%u nodes), %d CUs, %d blocks x 256, %d iters\n", mb, n_nodes, num_cu, blocks, iters);
+    if (argc > 2) {  // calibration mode for FETCH_SIZE: one streaming pass, one random-gather pass
+        hipLaunchKernelGGL(k_stream, dim3(blocks), dim3(256), 0, 0, d_nodes, (size_t)n_nodes * 4, d_out);
+        CK(hipDeviceSynchronize());
+        printf("k_stream read %.1f MB\n", n_nodes * 64.0 / 1e6);
+        hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, d_nodes, n_nodes, iters, d_out);
+        CK(hipDeviceSynchronize());
+        printf("k<0> gathered %.1f MB of 64-B nodes (%d x 256 x %d visits)\n", (double)blocks * 256 * iters * 64 / 1e6, blocks, iters);
+        return 0;
+    }
     run<0>("0 lane-private node, 4 x dwordx4", d_nodes, n_nodes, d_out, blocks, iters, num_cu);
     run<1>("1 quad shares node, 4 x dwordx4", d_nodes, n_nodes, d_out, blocks, iters, num_cu);
     run<5>("5 wave shares node, 4 x dwordx4", d_nodes, n_nodes, d_out, blocks, iters, num_cu);
