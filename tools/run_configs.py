@@ -1,0 +1,98 @@
+"""Runs the BASELINE.json configurations that fit one GPU and writes
+profiles/<tag>/configs.json: GPU time, CPU-oracle time on a bounded sample,
+and film agreement where both sides render the same passes.
+usage (on the GPU box): python tools/run_configs.py <out.json> [c1 c3 c4 c5]"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.binding import OracleScene  # noqa: E402
+from raytracer_amd import Context, scenes  # noqa: E402
+
+THREADS = max(1, min(16, len(os.sched_getaffinity(0))))
+
+
+def agree(film, ref):
+    a, b = film[..., :3].astype(np.float64), ref[..., :3].astype(np.float64)
+    err = np.abs(a - b)
+    return {"rel_rmse": float(np.sqrt((err ** 2).mean()) / (np.sqrt((b ** 2).mean()) + 1e-30)),
+            "max_abs": float(err.max()),
+            "frac_pixels_rel_gt_1e-3": float(((err / (np.abs(b) + 1e-3)).max(-1) > 1e-3).mean())}
+
+
+def gpu_render(scene, W, H, depth, spp, seed=0):
+    t0 = time.perf_counter()
+    ctx = Context(scene, W, H, max_depth=depth, seed=seed)
+    setup = time.perf_counter() - t0
+    ctx.set_camera(scene.camera)
+    ctx.render(1)
+    ctx.reset_accumulation()
+    s0 = ctx.stats()
+    t0 = time.perf_counter()
+    ctx.render(spp)
+    ctx.synchronize()
+    el = time.perf_counter() - t0
+    s1 = ctx.stats()
+    film = ctx.read_film()
+    rays = (s1["closest_rays"] - s0["closest_rays"]) + (s1["shadow_rays"] - s0["shadow_rays"])
+    res = {"seconds": el, "spp": spp, "samples_per_sec": W * H * spp / el, "mrays_per_sec": rays / el / 1e6,
+           "ms_per_pass": el / spp * 1e3, "setup_seconds": setup, "bvh_build_ms": s1["bvh_build_ms"],
+           "n_triangles": s1["n_triangles"], "bvh_max_depth": s1["bvh_max_depth"]}
+    ctx.close()
+    return film, res
+
+
+def cpu_render(scene, W, H, depth, spp, seed=0):
+    orc = OracleScene(scene)
+    t0 = time.perf_counter()
+    film, cnt = orc.render(scene.camera, W, H, depth, seed, spp, threads=THREADS)
+    el = time.perf_counter() - t0
+    return film, {"seconds": el, "spp": spp, "threads": THREADS, "samples_per_sec": W * H * spp / el,
+                  "mrays_per_sec": (cnt["closest"] + cnt["shadow"]) / el / 1e6}
+
+
+def main():
+    out_path = sys.argv[1]
+    which = sys.argv[2:] or ["c1", "c3", "c4", "c5"]
+    out = {"cpu_threads": THREADS}
+    if "c1" in which:
+        s = scenes.cornell_box()
+        film, g = gpu_render(s, 512, 512, 4, 16)
+        ref, c = cpu_render(s, 512, 512, 4, 16)
+        out["c1_cornell_512_16spp_d4"] = {"gpu": g, "cpu_oracle": c, "agreement": agree(film, ref)}
+        print("c1", json.dumps(out["c1_cornell_512_16spp_d4"]), flush=True)
+    if "c3" in which or "c4" in which:
+        sp = scenes.sponza_class()
+    if "c3" in which:
+        film64, g = gpu_render(sp, 1920, 1080, 8, 64)
+        film4, g4 = gpu_render(sp, 1920, 1080, 8, 4)
+        ref4, c = cpu_render(sp, 1920, 1080, 8, 4)
+        c["extrapolated_seconds_64spp"] = c["seconds"] * 16
+        out["c3_sponza_1080p_64spp_d8"] = {"gpu": g, "gpu_4spp": g4, "cpu_oracle_4spp": c, "agreement_4spp": agree(film4, ref4)}
+        print("c3", json.dumps(out["c3_sponza_1080p_64spp_d8"]), flush=True)
+    if "c4" in which:
+        film, g = gpu_render(sp, 3840, 2160, 8, 1024)
+        out["c4_sponza_4k_1024spp_1gpu"] = {"gpu": g, "finite": bool(np.isfinite(film).all()), "mean_rgb": film[..., :3].mean((0, 1)).tolist()}
+        print("c4", json.dumps(out["c4_sponza_4k_1024spp_1gpu"]), flush=True)
+    if "c5" in which:
+        t0 = time.perf_counter()
+        b = scenes.bistro_class()
+        gen = time.perf_counter() - t0
+        film, g = gpu_render(b, 1920, 1080, 12, 4)
+        g["extrapolated_seconds_256spp"] = g["seconds"] * 64
+        fs, gs = gpu_render(b, 240, 136, 12, 1, seed=4)
+        rs, c = cpu_render(b, 240, 136, 12, 1, seed=4)
+        out["c5_bistro_1080p_d12_65lights"] = {"scene_gen_seconds": gen, "n_lights": len(b.lights), "gpu_4spp": g,
+                                               "cpu_oracle_240x136_1spp": c, "agreement_240x136": agree(fs, rs),
+                                               "finite": bool(np.isfinite(film).all())}
+        print("c5", json.dumps(out["c5_bistro_1080p_d12_65lights"]), flush=True)
+    json.dump(out, open(out_path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
