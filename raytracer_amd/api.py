@@ -75,6 +75,15 @@ def load_library():
     if not os.path.exists(_LIB_PATH):
         raise RuntimeError(f"{_LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
                            "(or __graft_entry__.build()); there is no CPU fallback")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64, and a
+    # process that loads the system one first and PyTorch's afterwards ends up
+    # with no visible GPU in PyTorch.  Importing torch first makes this
+    # library bind to the runtime torch uses (set RT_HIP_NO_TORCH=1 to skip).
+    if os.environ.get("RT_HIP_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     lib = C.CDLL(_LIB_PATH)
     vp, fp, ip, up = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_uint32)
     lib.rt_create.argtypes = [C.POINTER(rt_scene_desc), C.POINTER(rt_params), C.POINTER(vp)]
