@@ -83,8 +83,12 @@ typedef struct rt_params {
     uint64_t seed;
     int32_t device;        /* HIP device ordinal */
     int32_t rank, world;   /* world 0 or 1 -> whole film */
-    uint32_t max_rays;     /* capacity of rt_trace_* host-pointer calls; 0 -> width*height */
+    uint32_t flags;        /* rt_flags; 0 = defaults */
 } rt_params;
+
+enum rt_flags {
+    RT_FLAG_HOST_BVH = 1   /* build the LBVH with the host builder instead of on the GPU (same tree) */
+};
 
 typedef struct rt_stats {
     uint64_t closest_rays;     /* closest-hit rays traced since create/reset */
@@ -96,11 +100,12 @@ typedef struct rt_stats {
     uint32_t n_local_pixels;   /* pixels of this rank's tiles */
     float last_trace_ms;       /* device time of the last rt_trace_* kernel (HIP events) */
     float last_render_ms;      /* device time of the last rt_render call */
-    float bvh_build_ms;        /* host LBVH build, wall */
+    float bvh_build_ms;        /* LBVH build (GPU or host) including its uploads, wall */
 } rt_stats;
 
 /* Replaces Integrator::Integrator (src/cpu/Integrator.cpp:7-15): builds the
- * LBVH of src/scene/BVH.cpp:287-336 on the host, uploads scene and film. */
+ * LBVH of src/scene/BVH.cpp:287-336 (on the GPU by default), uploads scene
+ * and film. */
 int rt_create(const rt_scene_desc* scene, const rt_params* params, rt_ctx** out);
 void rt_destroy(rt_ctx* ctx);
 /* Error text of the last failed call on ctx (ctx may be null for rt_create). */

@@ -63,7 +63,7 @@ uint32_t find_split(const std::vector<Prim>& p, uint32_t start, uint32_t end) {
 }  // namespace
 
 void build_lbvh(const float* pos, uint32_t stride, const uint32_t* indices, uint32_t n_indices,
-                const int32_t* tri_model, LbvhResult& out, size_t bfs_prefix) {
+                const int32_t* tri_model, LbvhResult& out, uint32_t top_levels) {
     const uint32_t T = n_indices / 3;
     auto P = [&](uint32_t vi) { return reinterpret_cast<const float*>(reinterpret_cast<const char*>(pos) + (size_t)vi * stride); };
     const float inf = std::numeric_limits<float>::infinity();
@@ -108,6 +108,7 @@ void build_lbvh(const float* pos, uint32_t stride, const uint32_t* indices, uint
     struct Item { uint32_t node, start, end; int32_t depth; };
     std::vector<Item> stack;
     std::vector<uint32_t> leaf_slot(T ? 2 * (size_t)T - 1 : 1, 0);
+    std::vector<uint32_t> node_start(T ? 2 * (size_t)T - 1 : 1, 0);  // first sorted leaf under each node
     RefNode blank{};
     blank.left = blank.right = blank.tri = blank.model = -1;
     ref.push_back(blank);
@@ -117,6 +118,7 @@ void build_lbvh(const float* pos, uint32_t stride, const uint32_t* indices, uint
         Item it = stack.back();
         stack.pop_back();
         if (it.depth > out.max_depth) out.max_depth = it.depth;
+        node_start[it.node] = it.start;
         if (it.start == it.end) {
             RefNode& n = ref[it.node];
             n.leaf = 1;
@@ -151,8 +153,14 @@ void build_lbvh(const float* pos, uint32_t stride, const uint32_t* indices, uint
     }
     for (int k = 0; k < 3; ++k) { out.root_min[k] = ref[0].bmin[k]; out.root_max[k] = ref[0].bmax[k]; }
 
-    // Device layout: inner nodes renumbered compactly in reference order,
-    // triangles in leaf order.
+    // Device layout.  Triangles in leaf (sorted) order.  Inner nodes: a node
+    // above level top_levels sits at its heap index (root 0, children 2h+1 and
+    // 2h+2: the block the traversal kernels keep in LDS; slots of absent nodes
+    // stay unused), a deeper node at (2^top_levels - 1) + its preorder rank
+    // among the inner nodes, so that a node's left child follows it directly
+    // (parent and near child often share a 128-byte line).  The preorder rank
+    // of the node over sorted leaves [start, end] is start + the number of
+    // left turns on the path from the root.
     out.tris.resize(T);
     for (uint32_t s = 0; s < T; ++s) {
         DevTri& d = out.tris[s];
@@ -165,10 +173,27 @@ void build_lbvh(const float* pos, uint32_t stride, const uint32_t* indices, uint
         d.id0 = p.model;
         d.pad = 0;
     }
-    std::vector<int32_t> link(ref.size());
-    int32_t n_inner = 0;
-    for (size_t i = 0; i < ref.size(); ++i) link[i] = ref[i].leaf ? ~(int32_t)leaf_slot[i] : n_inner++;
-    out.nodes.assign((size_t)n_inner, DevNode{});
+    const size_t top_slots = ((size_t)1 << top_levels) - 1;
+    std::vector<int32_t> link(ref.size(), 0);
+    {
+        struct W { uint32_t node, start, lturns, depth; size_t heap; };
+        std::vector<W> st;
+        if (T) st.push_back({0, 0, 0, 0, 0});
+        while (!st.empty()) {
+            W w = st.back();
+            st.pop_back();
+            const RefNode& n = ref[w.node];
+            if (n.leaf) {
+                link[w.node] = ~(int32_t)leaf_slot[w.node];
+                continue;
+            }
+            const uint32_t rank = w.start + w.lturns;
+            link[w.node] = (int32_t)(w.depth < top_levels ? w.heap : top_slots + rank);
+            st.push_back({(uint32_t)n.right, node_start[n.right], w.lturns, w.depth + 1, 2 * w.heap + 2});
+            st.push_back({(uint32_t)n.left, w.start, w.lturns + 1, w.depth + 1, 2 * w.heap + 1});
+        }
+    }
+    out.nodes.assign(T > 1 ? top_slots + (T - 1) : 0, DevNode{});
     for (size_t i = 0; i < ref.size(); ++i) {
         if (ref[i].leaf || ref[i].left < 0) continue;
         DevNode& d = out.nodes[link[i]];
@@ -179,41 +204,6 @@ void build_lbvh(const float* pos, uint32_t stride, const uint32_t* indices, uint
         d.pad[0] = d.pad[1] = 0;
     }
     out.root_link = T ? link[0] : 0;
-
-    // Renumber the inner nodes: the first bfs_prefix in breadth-first order
-    // from the root (a set of top-most nodes, which the traversal kernels keep
-    // in LDS), the rest in the order above, where a node's left child follows
-    // it directly (parent and near child often share a 128-byte line).
-    const size_t NI = out.nodes.size();
-    if (NI > 1 && out.root_link >= 0 && bfs_prefix > 0) {
-        std::vector<int32_t> renum(NI, -1);
-        std::vector<int32_t> order;
-        order.reserve(NI);
-        order.push_back(out.root_link);
-        renum[out.root_link] = 0;
-        for (size_t head = 0; head < order.size() && order.size() < bfs_prefix; ++head) {
-            const DevNode& d = out.nodes[order[head]];
-            for (int32_t ch : {d.left, d.right})
-                if (ch >= 0 && renum[ch] < 0 && order.size() < bfs_prefix) {
-                    renum[ch] = (int32_t)order.size();
-                    order.push_back(ch);
-                }
-        }
-        for (size_t i = 0; i < NI; ++i)
-            if (renum[i] < 0) {
-                renum[i] = (int32_t)order.size();
-                order.push_back((int32_t)i);
-            }
-        std::vector<DevNode> moved(NI);
-        for (size_t k = 0; k < NI; ++k) {
-            DevNode d = out.nodes[order[k]];
-            if (d.left >= 0) d.left = renum[d.left];
-            if (d.right >= 0) d.right = renum[d.right];
-            moved[k] = d;
-        }
-        out.nodes.swap(moved);
-        out.root_link = 0;
-    }
 }
 
 }  // namespace rt

@@ -40,7 +40,7 @@ static_assert(sizeof(DevTri) == 48, "DevTri must be 48 bytes");
 
 struct LbvhResult {
     std::vector<RefNode> ref;     // 2T-1 nodes, root = 0
-    std::vector<DevNode> nodes;   // T-1 inner nodes (empty when T == 1)
+    std::vector<DevNode> nodes;   // (2^top_levels - 1) + (T - 1) slots (empty when T == 1)
     std::vector<DevTri> tris;     // T triangles in leaf (Morton) order
     int32_t root_link = 0;        // link of the root (inner index or ~slot)
     float root_min[3], root_max[3];
@@ -48,10 +48,10 @@ struct LbvhResult {
 };
 
 // pos: strided vertex positions; indices already offset; tri_model per triangle.
-// The first bfs_prefix inner nodes of out.nodes are the top-most ones in
-// breadth-first order (the part the kernels stage in LDS).
+// Inner nodes above level top_levels are stored at their heap index (the part
+// the kernels stage in LDS), deeper ones after them in preorder.
 void build_lbvh(const float* pos, uint32_t pos_stride_bytes, const uint32_t* indices, uint32_t n_indices,
-                const int32_t* tri_model, LbvhResult& out, size_t bfs_prefix);
+                const int32_t* tri_model, LbvhResult& out, uint32_t top_levels);
 
 uint32_t expand_bits(uint32_t v);
 uint32_t morton3d(float x, float y, float z);

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../include/rt_hip.h"
+#include "lbvh_device.h"
 #include "lbvh_host.h"
 #include "shade.h"
 
@@ -41,7 +42,11 @@ struct rt_ctx {
     uint32_t n_local_tiles = 0, n_slots = 0, n_valid = 0;
 
     // geometry
-    LbvhResult bvh;
+    LbvhResult bvh;            // host build (RT_FLAG_HOST_BVH)
+    DeviceLbvh dbvh;           // GPU build (default)
+    bool device_built = false;
+    uint32_t n_triangles = 0, n_ref_nodes = 0;
+    int32_t bvh_max_depth = 0;
     float4* d_nodes = nullptr;
     float4* d_tris = nullptr;
     int32_t* d_ovf = nullptr;
@@ -321,6 +326,7 @@ void rt_destroy(rt_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
     for (void* p : c->allocs) (void)hipFree(p);
+    c->dbvh.release();
     for (hipEvent_t e : c->ev_shade) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_acc) (void)hipEventDestroy(e);
     if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
@@ -401,13 +407,54 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     HIP_TRY(c, hipEventCreate(&c->ev0));
     HIP_TRY(c, hipEventCreate(&c->ev1));
 
-    // ---- BVH
+    // ---- BVH: built on the GPU unless the caller asks for the host builder
     auto t0 = std::chrono::steady_clock::now();
-    build_lbvh(sd->pos, sd->pos_stride ? sd->pos_stride : 12, sd->indices, sd->n_indices, sd->tri_model, c->bvh, RT_TOP_NODES);
-    c->bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
     int r;
-    if ((r = dev_upload(c, &c->d_nodes, reinterpret_cast<const float4*>(c->bvh.nodes.data()), c->bvh.nodes.size() * 4))) return r;
-    if ((r = dev_upload(c, &c->d_tris, reinterpret_cast<const float4*>(c->bvh.tris.data()), c->bvh.tris.size() * 3))) return r;
+    const uint32_t pstride = sd->pos_stride ? sd->pos_stride : 12;
+    float rmin[3], rmax[3];
+    int32_t root_link;
+    size_t n_node_slots;
+    c->n_triangles = T;
+    c->n_ref_nodes = 2 * T - 1;
+    if (pr->flags & RT_FLAG_HOST_BVH) {
+        build_lbvh(sd->pos, pstride, sd->indices, sd->n_indices, sd->tri_model, c->bvh, RT_TOP_LEVELS);
+        if ((r = dev_upload(c, &c->d_nodes, reinterpret_cast<const float4*>(c->bvh.nodes.data()), c->bvh.nodes.size() * 4))) return r;
+        if ((r = dev_upload(c, &c->d_tris, reinterpret_cast<const float4*>(c->bvh.tris.data()), c->bvh.tris.size() * 3))) return r;
+        root_link = c->bvh.root_link;
+        n_node_slots = c->bvh.nodes.size();
+        c->bvh_max_depth = c->bvh.max_depth;
+        for (int k = 0; k < 3; ++k) { rmin[k] = c->bvh.root_min[k]; rmax[k] = c->bvh.root_max[k]; }
+    } else {
+        std::vector<float> packed((size_t)sd->n_vertices * 3);
+        for (uint32_t v = 0; v < sd->n_vertices; ++v) {
+            const float* q = strided(sd->pos, pstride, v);
+            packed[3 * (size_t)v] = q[0]; packed[3 * (size_t)v + 1] = q[1]; packed[3 * (size_t)v + 2] = q[2];
+        }
+        float* d_pos = nullptr;
+        uint32_t* d_idx = nullptr;
+        int32_t* d_tm = nullptr;
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_pos), packed.size() * sizeof(float)));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_idx), (size_t)sd->n_indices * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_tm), (size_t)T * sizeof(int32_t)));
+        HIP_TRY(c, hipMemcpy(d_pos, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_idx, sd->indices, (size_t)sd->n_indices * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(c, hipMemcpy(d_tm, sd->tri_model, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice));
+        std::string berr;
+        int br = build_lbvh_device(d_pos, d_idx, sd->n_indices, d_tm, RT_TOP_LEVELS, c->stream, &c->dbvh, &berr);
+        (void)hipFree(d_pos); (void)hipFree(d_idx); (void)hipFree(d_tm);
+        if (br != 0) {
+            c->err = "GPU LBVH build: " + berr;
+            return RT_ERR_HIP;
+        }
+        c->device_built = true;
+        c->d_nodes = c->dbvh.nodes;
+        c->d_tris = c->dbvh.tris;
+        root_link = c->dbvh.root_link;
+        n_node_slots = c->dbvh.n_node_slots;
+        c->bvh_max_depth = c->dbvh.max_depth;
+        for (int k = 0; k < 3; ++k) { rmin[k] = c->dbvh.root_min[k]; rmax[k] = c->dbvh.root_max[k]; }
+    }
+    c->bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
     // persistent traversal grid: as many workgroups per CU as LDS and registers admit
     int bpc = 0;
@@ -415,20 +462,20 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     if (bpc < 1) bpc = 1;
     c->grid_trace = (uint32_t)c->num_cu * (uint32_t)bpc;
     c->grid_exact = 8;
-    const uint32_t ovf_levels = (uint32_t)std::max(1, c->bvh.max_depth + 2 - RT_STACK_LDS);
+    const uint32_t ovf_levels = (uint32_t)std::max(1, c->bvh_max_depth + 2 - RT_STACK_LDS);
     const uint32_t ovf_stride = c->grid_trace * RT_TBLOCK;
     if ((r = dev_alloc(c, &c->d_ovf, (size_t)ovf_levels * ovf_stride))) return r;
     c->ts.nodes = c->d_nodes;
     c->ts.tris = c->d_tris;
-    c->ts.root_link = c->bvh.root_link;
-    c->ts.n_nodes = (int32_t)c->bvh.nodes.size();
-    for (int k = 0; k < 3; ++k) { c->ts.rmin[k] = c->bvh.root_min[k]; c->ts.rmax[k] = c->bvh.root_max[k]; }
+    c->ts.root_link = root_link;
+    c->ts.n_nodes = (int32_t)n_node_slots;
+    for (int k = 0; k < 3; ++k) { c->ts.rmin[k] = rmin[k]; c->ts.rmax[k] = rmax[k]; }
     c->ts.ovf = c->d_ovf;
     c->ts.ovf_stride = ovf_stride;
     c->ts.ovf_levels = ovf_levels;
     c->ts.tame = 1;
     for (int k = 0; k < 3; ++k)
-        if (!(std::fabs(c->bvh.root_min[k]) < 1e30f) || !(std::fabs(c->bvh.root_max[k]) < 1e30f)) c->ts.tame = 0;
+        if (!(std::fabs(rmin[k]) < 1e30f) || !(std::fabs(rmax[k]) < 1e30f)) c->ts.tame = 0;
 
     // ---- shading tables: per-triangle attribute blocks, 3 x (normal uv tangent binormal)
     {
@@ -770,10 +817,22 @@ int rt_trace_occluded(rt_ctx* c, uint32_t n, const float* rays, int32_t* status)
 int rt_get_bvh(rt_ctx* c, uint32_t* n_nodes, float* boxes, int32_t* left, int32_t* right, int32_t* tri, int32_t* model,
                int32_t* leaf) {
     if (!c || !n_nodes) return RT_ERR_ARG;
-    const auto& ref = c->bvh.ref;
-    *n_nodes = (uint32_t)ref.size();
+    const size_t NN = c->n_ref_nodes;
+    *n_nodes = (uint32_t)NN;
     if (!boxes) return RT_OK;
     if (!left || !right || !tri || !model || !leaf) return RT_ERR_ARG;
+    if (c->device_built) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        const LbvhRefArrays& ra = c->dbvh.ref;
+        HIP_TRY(c, hipMemcpy(boxes, ra.boxes, NN * 6 * sizeof(float), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(left, ra.left, NN * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(right, ra.right, NN * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(tri, ra.tri, NN * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(model, ra.model, NN * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemcpy(leaf, ra.leaf, NN * sizeof(int32_t), hipMemcpyDeviceToHost));
+        return RT_OK;
+    }
+    const auto& ref = c->bvh.ref;
     for (size_t i = 0; i < ref.size(); ++i) {
         for (int k = 0; k < 3; ++k) { boxes[6 * i + k] = ref[i].bmin[k]; boxes[6 * i + 3 + k] = ref[i].bmax[k]; }
         left[i] = ref[i].left; right[i] = ref[i].right; tri[i] = ref[i].tri; model[i] = ref[i].model; leaf[i] = ref[i].leaf;
@@ -786,7 +845,7 @@ int rt_lbvh_host(const float* pos, uint32_t pos_stride, const uint32_t* indices,
     if (!pos || !indices || !tri_model || n_indices < 3 || n_indices % 3 || !boxes || !left || !right || !tri || !model || !leaf)
         return RT_ERR_ARG;
     LbvhResult res;
-    build_lbvh(pos, pos_stride ? pos_stride : 12, indices, n_indices, tri_model, res, 0);
+    build_lbvh(pos, pos_stride ? pos_stride : 12, indices, n_indices, tri_model, res, RT_TOP_LEVELS);
     if (max_depth) *max_depth = res.max_depth;
     for (size_t i = 0; i < res.ref.size(); ++i) {
         for (int k = 0; k < 3; ++k) { boxes[6 * i + k] = res.ref[i].bmin[k]; boxes[6 * i + 3 + k] = res.ref[i].bmax[k]; }
@@ -808,9 +867,9 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     out->closest_rays = rs[0];
     out->shadow_rays = rs[1];
     out->passes = c->frames;
-    out->n_nodes = (uint32_t)c->bvh.ref.size();
-    out->n_triangles = (uint32_t)c->bvh.tris.size();
-    out->bvh_max_depth = c->bvh.max_depth;
+    out->n_nodes = c->n_ref_nodes;
+    out->n_triangles = c->n_triangles;
+    out->bvh_max_depth = c->bvh_max_depth;
     out->n_local_pixels = c->n_valid;
     out->last_trace_ms = c->last_trace_ms;
     out->last_render_ms = c->last_render_ms;

@@ -18,8 +18,8 @@
 //
 // LDS (per 512-thread workgroup: 28 KB of nodes + 24 KB of stack, three
 // workgroups per CU):
-//  * the top of the tree: the first RT_TOP_NODES inner nodes in breadth-first
-//    order, as four SoA planes.  About half of all node visits land there;
+//  * the top of the tree: the inner nodes of levels 0..RT_TOP_LEVELS-1, which
+//    the builder stores at their heap index, as four SoA planes.  About half of all node visits land there;
 //    they were mostly L1 hits before, so the measured gain is small (a few
 //    percent on incoherent rays): what bounds the kernel is the rate at
 //    which the deep, cache-missing visits pull new lines from L2;
@@ -39,9 +39,10 @@ namespace rt {
 #ifndef RT_STACK_LDS
 #define RT_STACK_LDS 12
 #endif
-#ifndef RT_TOP_NODES
-#define RT_TOP_NODES 512    // inner nodes kept in LDS (56 B each): levels 0-8 of a full tree
+#ifndef RT_TOP_LEVELS
+#define RT_TOP_LEVELS 9     // tree levels whose inner nodes are kept in LDS (56 B per slot)
 #endif
+#define RT_TOP_NODES ((1 << RT_TOP_LEVELS) - 1)
 // vote thresholds (lanes of 64)
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 20   // refill when at least this many lanes are idle
@@ -57,7 +58,7 @@ struct TraceScene {
     const float4* nodes;   // 4 float4 per inner node (DevNode)
     const float4* tris;    // 3 float4 per triangle (DevTri)
     int32_t root_link;
-    int32_t n_nodes;       // inner nodes
+    int32_t n_nodes;       // node slots
     float rmin[3], rmax[3];
     int32_t* ovf;          // overflow stack, [level - RT_STACK_LDS][grid thread]
     uint32_t ovf_stride;   // threads in the persistent grid

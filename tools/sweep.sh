@@ -11,7 +11,7 @@ mode=$1; shift
 if [ "$mode" = build ]; then
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
-    (cd $R/raytracer_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-function $flags -shared -o $V/librt_$name.so rt_hip.hip lbvh_host.cpp) &
+    (mkdir -p $V/obj_$name && cd $R/raytracer_amd/csrc && make -s lbvh_host.o lbvh_device.o && make -s OBJ=$V/obj_$name OUT=$V/librt_$name.so EXTRA="$flags" $V/librt_$name.so) &
   done
   wait
   ls -la $V
