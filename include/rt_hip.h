@@ -38,7 +38,17 @@ enum rt_light_type { RT_LIGHT_POINT = 0, RT_LIGHT_ENV = 3 };
 typedef struct rt_material {
     float diffuse_color[3];
     float roughness;
+    int32_t texture;         /* index into rt_scene_desc.textures (Material::_diffTexture,
+                                src/scene/Material.hpp:61), or -1 for none */
 } rt_material;
+
+/* Diffuse map: the RGBA8 image Material::setDiffuseTexture loads
+ * (src/scene/Material.cpp:92-96).  Level 0 only, row-major, 4 bytes a texel;
+ * the library builds the mip chain (2x2 box average, rounded). */
+typedef struct rt_texture {
+    int32_t width, height;
+    const uint8_t* rgba8;
+} rt_texture;
 
 /* PointLight{pos = light2world*(0,0,0,1), I} (src/lights/PointLight.cpp:9-18)
  * or EnvLight{RGBA32F lat-long image, scale} (src/lights/EnvLight.cpp:14-26). */
@@ -70,6 +80,8 @@ typedef struct rt_scene_desc {
     const rt_material* materials;                     /* one per model */
     uint32_t n_lights;
     const rt_light* lights;
+    uint32_t n_textures;
+    const rt_texture* textures;                       /* may be null when n_textures == 0 */
 } rt_scene_desc;
 
 /* Compile-time constants of the reference made parameters: frame size
@@ -126,6 +138,11 @@ int rt_render(rt_ctx* ctx, uint32_t n_passes);
  * RGBA32F film, row-major, y=0 at the top, width*height*4 floats.  Pixels of
  * other ranks' tiles are written as zero. */
 int rt_read_film(rt_ctx* ctx, float* rgba_out);
+/* Diagnostic: the UV differences (dUVx.xy, dUVy.xy, in film pixels) that the
+ * last pass handed to Material::computeBSDF for each primary hit
+ * (src/cpu/PathTracer.cpp:83-90), width*height*4 floats of this rank's pixels;
+ * zero where the primary ray missed or the scene has no textures. */
+int rt_read_primary_duv(rt_ctx* ctx, float* duv_out);
 
 /* This rank's packed tile slab on the device: n_tiles*tile*tile*4 floats,
  * tiles in increasing global tile index.  For gathering the film across ranks. */

@@ -19,6 +19,10 @@ class orc_light_desc(C.Structure):
                 ("env_rgba", C.POINTER(C.c_float)), ("env_w", C.c_int32), ("env_h", C.c_int32)]
 
 
+class orc_texture_desc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgba", C.POINTER(C.c_uint8))]
+
+
 def build():
     subprocess.check_call(["make", "-C", _DIR, "-s"])
 
@@ -34,14 +38,19 @@ def lib():
     u64p = C.POINTER(C.c_uint64)
     L.orc_create.restype = vp
     L.orc_create.argtypes = [C.c_uint32, fp, fp, fp, fp, fp, C.c_uint32, up, ip, C.c_uint32, fp, C.c_uint32,
-                             C.POINTER(orc_light_desc)]
+                             C.POINTER(orc_light_desc), ip, C.c_uint32, C.POINTER(orc_texture_desc)]
+    L.orc_texture_levels.argtypes = [vp, C.c_int]
+    L.orc_texture_level.argtypes = [vp, C.c_int, C.c_int, ip, ip, C.POINTER(C.c_uint8)]
+    L.orc_texture_bilinear.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp]
+    L.orc_texture_trilinear.argtypes = [vp, C.c_int, C.c_float, C.c_float, fp, fp, fp]
     L.orc_destroy.argtypes = [vp]
     L.orc_bvh_info.argtypes = [vp, up, ip]
     L.orc_bvh_nodes.argtypes = [vp, fp, ip, ip, ip, ip, ip]
     L.orc_intersect.argtypes = [vp, C.c_uint64, fp, fp, ip, ip, fp, fp, u64p, C.c_int]
     L.orc_occluded.argtypes = [vp, C.c_uint64, fp, ip, u64p]
     L.orc_brute_force.argtypes = [vp, C.c_uint64, fp, fp, ip]
-    L.orc_render.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, fp, u64p]
+    L.orc_render.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, fp, u64p,
+                             C.c_int, fp]
     L.orc_camera_rays.argtypes = [fp, C.c_int, C.c_int, fp]
     L.orc_morton3d.restype = C.c_uint32
     L.orc_morton3d.argtypes = [C.c_float] * 3
@@ -102,10 +111,19 @@ class OracleScene:
                 lights[k].env_rgba = _f(env)
                 lights[k].env_h, lights[k].env_w = env.shape[0], env.shape[1]
         mats = np.ascontiguousarray(s.materials, np.float32)
+        textures = list(getattr(s, "textures", []))
+        tex = (orc_texture_desc * max(1, len(textures)))()
+        for k, t in enumerate(textures):
+            t = np.ascontiguousarray(t, np.uint8)
+            self._keep.append(t)
+            tex[k].height, tex[k].width = t.shape[0], t.shape[1]
+            tex[k].rgba = t.ctypes.data_as(C.POINTER(C.c_uint8))
+        mt = getattr(s, "material_texture", None)
+        mt = np.full(s.n_models, -1, np.int32) if mt is None else np.ascontiguousarray(mt, np.int32)
         self._h = L.orc_create(s.pos.shape[0], _f(s.pos), _f(s.normal), _f(s.uv),
                                _f(s.tangent) if use_frame else None, _f(s.binormal) if use_frame else None,
                                s.indices.size, s.indices.ctypes.data_as(C.POINTER(C.c_uint32)), _i(s.tri_model),
-                               s.n_models, _f(mats), len(s.lights), lights)
+                               s.n_models, _f(mats), len(s.lights), lights, _i(mt), len(textures), tex)
         self.scene = s
 
     def __del__(self):
@@ -153,13 +171,35 @@ class OracleScene:
         self._L.orc_brute_force(self._h, n, _f(rays), _f(t), _i(id1))
         return t, id1
 
-    def render(self, cam, W, H, max_depth, seed, n_passes, threads=8, film=None, first_pass=0):
+    def render(self, cam, W, H, max_depth, seed, n_passes, threads=8, film=None, first_pass=0, tile_size=64, duv=None):
+        """duv: optional (H, W, 4) float32 array receiving dUVx, dUVy of each primary hit."""
         if film is None:
             film = np.zeros((H, W, 4), np.float32)
         cnt = (C.c_uint64 * 2)()
         c = cam.packed()
-        self._L.orc_render(self._h, _f(c), W, H, max_depth, seed, first_pass, n_passes, threads, _f(film), cnt)
+        self._L.orc_render(self._h, _f(c), W, H, max_depth, seed, first_pass, n_passes, threads, _f(film), cnt, tile_size,
+                            None if duv is None else _f(duv))
         return film, {"closest": cnt[0], "shadow": cnt[1]}
+
+    def texture_level(self, t, level):
+        w, h = C.c_int32(), C.c_int32()
+        self._L.orc_texture_level(self._h, t, level, C.byref(w), C.byref(h), None)
+        out = np.empty((h.value, w.value, 4), np.uint8)
+        self._L.orc_texture_level(self._h, t, level, C.byref(w), C.byref(h), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return out
+
+    def texture_levels(self, t):
+        return self._L.orc_texture_levels(self._h, t)
+
+    def texture_bilinear(self, t, level, u, v):
+        rgb = np.zeros(3, np.float32)
+        self._L.orc_texture_bilinear(self._h, t, level, u, v, _f(rgb))
+        return rgb
+
+    def texture_trilinear(self, t, u, v, duvx, duvy):
+        rgb = np.zeros(3, np.float32)
+        self._L.orc_texture_trilinear(self._h, t, u, v, _f(f3(*duvx)), _f(f3(*duvy)), _f(rgb))
+        return rgb
 
     def light_sample(self, l, p, u0, u1):
         in3, li3 = np.zeros(3, np.float32), np.zeros(3, np.float32)

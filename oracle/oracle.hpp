@@ -697,9 +697,77 @@ struct Light {
     }
 };
 
+// RGBA8 texture with its mip chain (the reference's spImage4b; its loader
+// and filters live in the absent Mango library, so the definitions below are
+// build-defined): level k+1 is the 2x2 box average of level k in integers,
+// (a+b+c+d+2)>>2 per channel, sizes max(1, w>>1).
+struct Texture {
+    std::vector<std::vector<uint8_t>> levels;
+    std::vector<int> w, h;
+    void build(const uint8_t* rgba, int W, int H) {
+        levels.clear(); w.clear(); h.clear();
+        levels.emplace_back(rgba, rgba + (size_t)W * H * 4);
+        w.push_back(W); h.push_back(H);
+        while (w.back() > 1 || h.back() > 1) {
+            int pw = w.back(), ph = h.back(), nw = std::max(1, pw >> 1), nh = std::max(1, ph >> 1);
+            const std::vector<uint8_t>& src = levels.back();
+            std::vector<uint8_t> dst((size_t)nw * nh * 4);
+            for (int y = 0; y < nh; ++y)
+                for (int x = 0; x < nw; ++x) {
+                    int x0 = std::min(2 * x, pw - 1), x1 = std::min(2 * x + 1, pw - 1);
+                    int y0 = std::min(2 * y, ph - 1), y1 = std::min(2 * y + 1, ph - 1);
+                    for (int c = 0; c < 4; ++c) {
+                        int sum = src[((size_t)y0 * pw + x0) * 4 + c] + src[((size_t)y0 * pw + x1) * 4 + c] +
+                                  src[((size_t)y1 * pw + x0) * 4 + c] + src[((size_t)y1 * pw + x1) * 4 + c];
+                        dst[((size_t)y * nw + x) * 4 + c] = (uint8_t)((sum + 2) >> 2);
+                    }
+                }
+            levels.push_back(std::move(dst));
+            w.push_back(nw); h.push_back(nh);
+        }
+    }
+    // bilinear fetch of one level, channels in 0..255 (repeat wrap, texel centres at +0.5)
+    vec3 bilinear(int level, vec2 uv) const {
+        const int W = w[level], H = h[level];
+        const uint8_t* img = levels[level].data();
+        float x = uv.x * (float)W - 0.5f, y = uv.y * (float)H - 0.5f;
+        float fx0 = std::floor(x), fy0 = std::floor(y);
+        float fx = x - fx0, fy = y - fy0;
+        int x0 = (int)fx0, y0 = (int)fy0;
+        auto wrap = [](int i, int n) { i %= n; return i < 0 ? i + n : i; };
+        int xa = wrap(x0, W), xb = wrap(x0 + 1, W), ya = wrap(y0, H), yb = wrap(y0 + 1, H);
+        auto px = [&](int xx, int yy) {
+            const uint8_t* p = img + ((size_t)yy * W + xx) * 4;
+            return vec3{(float)p[0], (float)p[1], (float)p[2]};
+        };
+        vec3 top = px(xa, ya) * (1.0f - fx) + px(xb, ya) * fx;
+        vec3 bot = px(xa, yb) * (1.0f - fx) + px(xb, yb) * fx;
+        return top * (1.0f - fy) + bot * fy;
+    }
+    // stands in for filterLinear(*tex, uv, 0) (src/scene/Material.cpp:217)
+    vec3 filterLinear(vec2 uv) const { return bilinear(0, uv); }
+    // stands in for filterTrilinear(*tex, uv, dUVx, dUVy) (src/scene/Material.cpp:198):
+    // lod = log2 of the longer footprint axis in level-0 texels, two bilinear fetches
+    vec3 filterTrilinear(vec2 uv, vec2 dUVx, vec2 dUVy) const {
+        const float W = (float)w[0], H = (float)h[0];
+        float ax = dUVx.x * W, ay = dUVx.y * H, bx = dUVy.x * W, by = dUVy.y * H;
+        float lx = std::sqrt(ax * ax + ay * ay), ly = std::sqrt(bx * bx + by * by);
+        float rho = (lx < ly) ? ly : lx;
+        const int last = (int)levels.size() - 1;
+        float lod = 0.0f;
+        if (rho > 1.0f) lod = std::log2(rho);  // false for NaN
+        if (!(lod < (float)last)) lod = (float)last;
+        int l0 = (int)std::floor(lod);
+        int l1 = std::min(l0 + 1, last);
+        float f = lod - (float)l0;
+        return bilinear(l0, uv) * (1.0f - f) + bilinear(l1, uv) * f;
+    }
+};
+
 struct MaterialData {
     vec3 diffuseColor{1, 1, 1};
     float roughness = 0.5f;  // src/scene/Material.cpp:9
+    int texture = -1;        // index into Scene::textures, -1 = none (_diffTexture null)
 };
 
 struct Camera {
@@ -710,6 +778,7 @@ struct Camera {
 struct Scene {
     BVH bvh;
     std::vector<MaterialData> materials;  // one per model
+    std::vector<Texture> textures;
     std::vector<Light> lights;
     bool haveFrame = true;
 };
@@ -735,34 +804,38 @@ inline Ray cameraRay(const Camera& cam, int x, int y, int W, int H) {
     return Ray(cam.pos, normalize(ip));
 }
 
-// src/scene/Material.cpp:214-225 without a texture: colour = (255/255) * diffuseColor
+inline vec2 fract2(vec2 v) { return {v.x - std::floor(v.x), v.y - std::floor(v.y)}; }  // glm::fract
+
+// src/scene/Material.cpp:195-212: the primary hit filters the texture with
+// the quad's UV differences
+inline BSDF computeBSDF(const Scene& s, const Vertex& v, int model, vec2 dUVx, vec2 dUVy) {
+    const MaterialData& m = s.materials[model];
+    vec2 repeatUV = fract2(v.uv);
+    vec3 c = m.texture >= 0 ? s.textures[m.texture].filterTrilinear(repeatUV, dUVx, dUVy) : V3(255.0f);
+    c = c / 255.0f;
+    c = c * m.diffuseColor;
+    return BSDF(v, Diffuse(c, m.roughness));
+}
+// src/scene/Material.cpp:214-225: later bounces use the plain bilinear fetch
 inline BSDF computeBSDF(const Scene& s, const Vertex& v, int model) {
     const MaterialData& m = s.materials[model];
-    vec3 c = V3(255.0f) / 255.0f;
+    vec2 repeatUV = fract2(v.uv);
+    vec3 c = m.texture >= 0 ? s.textures[m.texture].filterLinear(repeatUV) : V3(255.0f);
+    c = c / 255.0f;
     c = c * m.diffuseColor;
     return BSDF(v, Diffuse(c, m.roughness));
 }
 
-// One pixel of src/cpu/PathTracer.cpp:36-160.  `frames` = passes already
-// accumulated; film is W*H RGBA32F, updated in place (the reference's
-// ping-pong pair reads the previous value of the same pixel only).
-inline void renderPixel(const Scene& s, const Camera& cam, int x, int y, int W, int H, int maxDepth,
-                        uint64_t seed, uint32_t pass, float frames, float* film, RenderCounters* rc) {
+// PASS 2 of src/cpu/PathTracer.cpp:70-160 for one pixel whose primary ray
+// hit: `vertex`/`bsdf` of the first hit come from the caller.  `frames` =
+// passes already accumulated; film is W*H RGBA32F, updated in place (the
+// reference's ping-pong pair reads the previous value of the same pixel only).
+inline void shadePixel(const Scene& s, int x, int y, int W, int maxDepth, uint64_t seed, uint32_t pass, float frames, float* film,
+                       Ray ray, Vertex vertex, BSDF bsdf, RenderCounters* rc) {
     const int L = (int)s.lights.size();
     const uint32_t pixel = (uint32_t)(y * W + x);
     float* out4 = film + (size_t)pixel * 4;
-    Ray ray = cameraRay(cam, x, y, W, H);
-    uint64_t nClosest = 1, nShadow = 0;
-    RayHit hit = s.bvh.intersect(ray);
-    if (!hit.status) {
-        vec3 Lm{0.f, 0.f, 0.f};
-        for (const Light& l : s.lights) Lm = Lm + l.le(ray);
-        out4[0] = Lm.x; out4[1] = Lm.y; out4[2] = Lm.z; out4[3] = 1.0f;
-        if (rc) rc->closest += nClosest;
-        return;
-    }
-    Vertex vertex = s.bvh.postIntersect(ray, hit, s.haveFrame);
-    BSDF bsdf = computeBSDF(s, vertex, hit.id0);
+    uint64_t nClosest = 0, nShadow = 0;
     vec3 out = -ray.dir;
     vec3 pixelColor{0.f, 0.f, 0.f};
     vec3 threshold{1.f, 1.f, 1.f};
@@ -806,7 +879,7 @@ inline void renderPixel(const Scene& s, const Camera& cam, int x, int y, int W, 
         threshold = threshold * (bsdfColor * std::fabs(dot(nextDir, vertex.normal)) / nextPDF);
         ray = Ray(vertex.pos, nextDir);
         nClosest++;
-        hit = s.bvh.intersect(ray);
+        RayHit hit = s.bvh.intersect(ray);
         if (hit.status) {
             vertex = s.bvh.postIntersect(ray, hit, s.haveFrame);
             bsdf = computeBSDF(s, vertex, hit.id0);
@@ -827,12 +900,78 @@ inline void renderPixel(const Scene& s, const Camera& cam, int x, int y, int W, 
     if (rc) { rc->closest += nClosest; rc->shadow += nShadow; }
 }
 
+// PathTracer::computeTile, src/cpu/PathTracer.cpp:17-164: 2x2 pixel quads,
+// PASS 1 traces the primary rays of a quad, PASS 2 shades the pixels that hit
+// with UV differences taken inside the quad.  vertexBlock lives for the whole
+// tile and is only overwritten by pixels that hit, so a quad pixel that
+// missed (or lies outside the film) contributes the UV of an earlier quad --
+// zero at the start of a tile (sVertex's members are taken as zero-initialised).
+inline void computeTile(const Scene& s, const Camera& cam, int startX, int startY, int W, int H, int tileSize, int maxDepth,
+                        uint64_t seed, uint32_t pass, float frames, float* film, RenderCounters* rc, float* duvOut = nullptr) {
+    bool statusBlock[4] = {false, false, false, false};
+    Vertex vertexBlock[4];
+    int modelBlock[4] = {0, 0, 0, 0};
+    Ray raysBlock[4];
+    const vec2 ptSize = {(float)W, (float)H};
+    for (int yBlock = startY; yBlock < startY + tileSize; yBlock += 2) {
+        if (yBlock >= H) break;
+        for (int xBlock = startX; xBlock < startX + tileSize; xBlock += 2) {
+            if (xBlock >= W) break;
+            for (int yB = 0; yB < 2; ++yB) {
+                int y = yBlock + yB;
+                if (y >= H) break;
+                for (int xB = 0; xB < 2; ++xB) {
+                    int x = xBlock + xB;
+                    if (x >= W) break;
+                    Ray r = cameraRay(cam, x, y, W, H);
+                    RayHit hit = s.bvh.intersect(r);
+                    if (rc) rc->closest += 1;
+                    int id = yB * 2 + xB;
+                    statusBlock[id] = hit.status;
+                    if (hit.status) {
+                        vertexBlock[id] = s.bvh.postIntersect(r, hit, s.haveFrame);
+                        modelBlock[id] = hit.id0;
+                        raysBlock[id] = r;
+                    } else {
+                        vec3 Lm{0.f, 0.f, 0.f};
+                        for (const Light& l : s.lights) Lm = Lm + l.le(r);
+                        float* o = film + ((size_t)y * W + x) * 4;
+                        o[0] = Lm.x; o[1] = Lm.y; o[2] = Lm.z; o[3] = 1.0f;
+                    }
+                }
+            }
+            for (int yB = 0; yB < 2; ++yB) {
+                int y = yBlock + yB;
+                if (y >= H) break;
+                for (int xB = 0; xB < 2; ++xB) {
+                    int x = xBlock + xB;
+                    if (x >= W) break;
+                    if (!statusBlock[yB * 2 + xB]) continue;
+                    const Vertex& vertex = vertexBlock[yB * 2 + xB];
+                    vec2 dUVx = {vertexBlock[yB * 2 + 1].uv.x - vertexBlock[yB * 2 + 0].uv.x,
+                                 vertexBlock[yB * 2 + 1].uv.y - vertexBlock[yB * 2 + 0].uv.y};
+                    vec2 dUVy = {vertexBlock[1 * 2 + xB].uv.x - vertexBlock[xB].uv.x,
+                                 vertexBlock[1 * 2 + xB].uv.y - vertexBlock[xB].uv.y};
+                    dUVx = {dUVx.x * ptSize.x, dUVx.y * ptSize.y};
+                    dUVy = {dUVy.x * ptSize.x, dUVy.y * ptSize.y};
+                    if (duvOut) {  // test hook: the differences this pixel's primary hit was filtered with
+                        float* o = duvOut + ((size_t)y * W + x) * 4;
+                        o[0] = dUVx.x; o[1] = dUVx.y; o[2] = dUVy.x; o[3] = dUVy.y;
+                    }
+                    BSDF bsdf = computeBSDF(s, vertex, modelBlock[yB * 2 + xB], dUVx, dUVy);
+                    shadePixel(s, x, y, W, maxDepth, seed, pass, frames, film, raysBlock[yB * 2 + xB], vertex, bsdf, rc);
+                }
+            }
+        }
+    }
+}
+
 // One sample pass over the film: src/cpu/Integrator.cpp:26-67 (64x64 tiles
 // pulled from an atomic counter by `threads` workers; the tile grid uses the
 // height for its y extent, where the reference's width only adds empty tiles).
 inline void renderPass(const Scene& s, const Camera& cam, int W, int H, int maxDepth, uint64_t seed,
-                       uint32_t pass, float frames, float* film, int threads, RenderCounters* rc) {
-    const int tileSize = 64;
+                       uint32_t pass, float frames, float* film, int threads, RenderCounters* rc, int tileSize = 64,
+                       float* duvOut = nullptr) {
     int tx = (W + tileSize - 1) / tileSize, ty = (H + tileSize - 1) / tileSize;
     std::atomic<int> tileCurr{0};
     int tileCount = tx * ty;
@@ -840,10 +979,7 @@ inline void renderPass(const Scene& s, const Camera& cam, int W, int H, int maxD
         for (;;) {
             int t = tileCurr++;
             if (t >= tileCount) break;
-            int sx = (t % tx) * tileSize, sy = (t / tx) * tileSize;
-            for (int y = sy; y < sy + tileSize && y < H; ++y)
-                for (int x = sx; x < sx + tileSize && x < W; ++x)
-                    renderPixel(s, cam, x, y, W, H, maxDepth, seed, pass, frames, film, rc);
+            computeTile(s, cam, (t % tx) * tileSize, (t / tx) * tileSize, W, H, tileSize, maxDepth, seed, pass, frames, film, rc, duvOut);
         }
     };
     if (threads <= 1) { worker(); return; }

@@ -14,6 +14,11 @@ struct orc_light_desc {
     int32_t env_w, env_h;
 };
 
+struct orc_texture_desc {
+    int32_t width, height;
+    const uint8_t* rgba;   // level 0, width*height*4 bytes
+};
+
 struct orc_scene {
     Scene s;
 };
@@ -24,7 +29,8 @@ orc_scene* orc_create(uint32_t n_vertices, const float* pos, const float* normal
                       const float* tangent, const float* binormal, uint32_t n_indices,
                       const uint32_t* indices, const int32_t* tri_model, uint32_t n_models,
                       const float* materials /* rgb + roughness per model */, uint32_t n_lights,
-                      const orc_light_desc* lights) {
+                      const orc_light_desc* lights, const int32_t* material_texture /* per model or null */,
+                      uint32_t n_textures, const orc_texture_desc* textures) {
     auto* o = new orc_scene();
     std::vector<Vertex> verts(n_vertices);
     for (uint32_t i = 0; i < n_vertices; ++i) {
@@ -43,7 +49,10 @@ orc_scene* orc_create(uint32_t n_vertices, const float* pos, const float* normal
     for (uint32_t m = 0; m < n_models; ++m) {
         o->s.materials[m].diffuseColor = {materials[4 * m], materials[4 * m + 1], materials[4 * m + 2]};
         o->s.materials[m].roughness = materials[4 * m + 3];
+        o->s.materials[m].texture = material_texture ? material_texture[m] : -1;
     }
+    o->s.textures.resize(n_textures);
+    for (uint32_t t = 0; t < n_textures; ++t) o->s.textures[t].build(textures[t].rgba, textures[t].width, textures[t].height);
     for (uint32_t l = 0; l < n_lights; ++l) {
         Light lt;
         lt.type = lights[l].type;
@@ -141,7 +150,8 @@ void orc_brute_force(const orc_scene* o, uint64_t n, const float* rays, float* t
 // [first_pass, first_pass+n_passes) into film (W*H*4 floats, read-modify-write).
 // ray_counts[2] = {closest-hit rays, shadow rays} (may be null).
 void orc_render(const orc_scene* o, const float* camera, int W, int H, int max_depth, uint64_t seed,
-                uint32_t first_pass, uint32_t n_passes, int threads, float* film, uint64_t* ray_counts) {
+                uint32_t first_pass, uint32_t n_passes, int threads, float* film, uint64_t* ray_counts, int tile_size,
+                float* duv_out /* W*H*4 or null: dUVx, dUVy of each primary hit (last pass), untouched where it missed */) {
     Camera cam;
     cam.pos = {camera[0], camera[1], camera[2]};
     cam.right = {camera[3], camera[4], camera[5]};
@@ -150,7 +160,7 @@ void orc_render(const orc_scene* o, const float* camera, int W, int H, int max_d
     RenderCounters rc;
     for (uint32_t p = 0; p < n_passes; ++p)
         renderPass(o->s, cam, W, H, max_depth, seed, first_pass + p, (float)(first_pass + p), film, threads,
-                   ray_counts ? &rc : nullptr);
+                   ray_counts ? &rc : nullptr, tile_size > 0 ? tile_size : 64, duv_out);
     if (ray_counts) { ray_counts[0] = rc.closest; ray_counts[1] = rc.shadow; }
 }
 
@@ -236,6 +246,22 @@ void orc_dist2d_sample(const float* data, int w, int h, float u0, float u1, floa
 float orc_dist2d_pdf(const float* data, int w, int h, float p0, float p1) {
     Distribution2D d(std::vector<float>(data, data + (size_t)w * h), w, h);
     return d.pdf({p0, p1});
+}
+
+// Texture hooks: mip level sizes / texels and the two filters (channels 0..255)
+int orc_texture_levels(const orc_scene* o, int t) { return (int)o->s.textures[t].levels.size(); }
+void orc_texture_level(const orc_scene* o, int t, int level, int32_t* w, int32_t* h, uint8_t* rgba_out) {
+    const Texture& tx = o->s.textures[t];
+    *w = tx.w[level]; *h = tx.h[level];
+    if (rgba_out) std::memcpy(rgba_out, tx.levels[level].data(), tx.levels[level].size());
+}
+void orc_texture_bilinear(const orc_scene* o, int t, int level, float u, float v, float* rgb) {
+    vec3 c = o->s.textures[t].bilinear(level, {u, v});
+    rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
+}
+void orc_texture_trilinear(const orc_scene* o, int t, float u, float v, const float* duvx, const float* duvy, float* rgb) {
+    vec3 c = o->s.textures[t].filterTrilinear({u, v}, {duvx[0], duvx[1]}, {duvy[0], duvy[1]});
+    rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z;
 }
 
 float orc_rng_u01(uint64_t seed, uint32_t pixel, uint32_t pass, uint32_t dim) {

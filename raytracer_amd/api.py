@@ -25,7 +25,11 @@ class RtError(RuntimeError):
 
 
 class rt_material(C.Structure):
-    _fields_ = [("diffuse_color", C.c_float * 3), ("roughness", C.c_float)]
+    _fields_ = [("diffuse_color", C.c_float * 3), ("roughness", C.c_float), ("texture", C.c_int32)]
+
+
+class rt_texture(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("rgba8", C.POINTER(C.c_uint8))]
 
 
 class rt_light(C.Structure):
@@ -43,7 +47,8 @@ class rt_scene_desc(C.Structure):
                 ("n_indices", C.c_uint32), ("indices", C.POINTER(C.c_uint32)),
                 ("tri_model", C.POINTER(C.c_int32)),
                 ("n_models", C.c_uint32), ("materials", C.POINTER(rt_material)),
-                ("n_lights", C.c_uint32), ("lights", C.POINTER(rt_light))]
+                ("n_lights", C.c_uint32), ("lights", C.POINTER(rt_light)),
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(rt_texture))]
 
 
 class rt_params(C.Structure):
@@ -67,6 +72,7 @@ EXPORTS = [
     "rt_read_film", "rt_film_slab", "rt_copy_film_slab", "rt_unpack_slabs", "rt_trace_closest",
     "rt_trace_occluded", "rt_trace_closest_dev", "rt_trace_occluded_dev", "rt_get_bvh", "rt_get_stats",
     "rt_synchronize", "rt_version", "rt_lbvh_host", "rt_morton3d", "rt_last_trace_ms", "rt_slab_floats", "rt_pack_slab",
+    "rt_read_primary_duv",
 ]
 
 
@@ -98,6 +104,7 @@ def load_library():
     lib.rt_reset_accumulation.argtypes = [vp]
     lib.rt_render.argtypes = [vp, C.c_uint32]
     lib.rt_read_film.argtypes = [vp, fp]
+    lib.rt_read_primary_duv.argtypes = [vp, fp]
     lib.rt_film_slab.argtypes = [vp, C.POINTER(vp), up, C.POINTER(C.c_uint64)]
     lib.rt_copy_film_slab.argtypes = [vp, vp, C.c_uint64]
     lib.rt_unpack_slabs.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, C.c_uint64, fp]
@@ -146,6 +153,13 @@ class Context:
         for m in range(s.n_models):
             mats[m].diffuse_color[:] = [float(x) for x in s.materials[m, :3]]
             mats[m].roughness = float(s.materials[m, 3])
+            mats[m].texture = int(s.material_texture[m])
+        textures = (rt_texture * max(1, len(s.textures)))()
+        for i, t in enumerate(s.textures):
+            t = np.ascontiguousarray(t, np.uint8)
+            self._keep.append(t)
+            textures[i].height, textures[i].width = t.shape[0], t.shape[1]
+            textures[i].rgba8 = t.ctypes.data_as(C.POINTER(C.c_uint8))
         lights = (rt_light * max(1, len(s.lights)))()
         for i, l in enumerate(s.lights):
             lights[i].type = l.type
@@ -169,6 +183,7 @@ class Context:
         d.tri_model = _iptr(s.tri_model)
         d.n_models, d.materials = s.n_models, mats
         d.n_lights, d.lights = len(s.lights), lights
+        d.n_textures, d.textures = len(s.textures), textures
         p = rt_params(width, height, max_depth, tile_size, seed, device, rank, world, RT_FLAG_HOST_BVH if host_bvh else 0)
         rc = self._lib.rt_create(C.byref(d), C.byref(p), C.byref(self._h))
         if rc != 0:
@@ -203,6 +218,12 @@ class Context:
     def read_film(self) -> np.ndarray:
         out = np.empty((self.height, self.width, 4), np.float32)
         self._check(self._lib.rt_read_film(self._h, _fptr(out)))
+        return out
+
+    def read_primary_duv(self) -> np.ndarray:
+        """(H, W, 4): dUVx.xy, dUVy.xy of the last pass's primary hits (zero where the ray missed)."""
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._lib.rt_read_primary_duv(self._h, _fptr(out)))
         return out
 
     def film_slab_info(self) -> Tuple[int, int, int]:

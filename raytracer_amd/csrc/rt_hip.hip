@@ -57,6 +57,12 @@ struct rt_ctx {
     float* d_tri_attr = nullptr;
     float4* d_materials = nullptr;
     DevLight* d_lights = nullptr;
+    int32_t* d_material_texture = nullptr;
+    DevTexture* d_textures = nullptr;
+    TexLevel* d_tex_levels = nullptr;
+    uchar4* d_texels = nullptr;
+    float4* d_duv = nullptr;
+    uint32_t n_textures = 0;
     std::vector<EnvTables> env;
     ShadeScene ss{};
     int n_lights = 0;
@@ -287,6 +293,9 @@ int run_pass(rt_ctx* c) {
         hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.rays, n, qin, cnt_in,
                            work + d, c->d_pass_deferred, c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v,
                            c->d_raystats);
+        if (d == 0 && c->n_textures && c->n_local_tiles)
+            hipLaunchKernelGGL(k_quad_duv, dim3(c->n_local_tiles), dim3(RT_BLOCK), 0, c->stream, c->pb, c->d_tri_attr, c->d_duv, c->tile,
+                               (float)c->params.width, (float)c->params.height);
         uint32_t* sqc = c->d_counts + (D + 1) + d;
         // shade(d) overwrites the parity-p buffers that shadow/accumulate(d-2) read
         if (L > 0 && d >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_acc[d - 2], 0));
@@ -369,6 +378,21 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         c->err = "rank must be in [0, world)";
         return RT_ERR_ARG;
     }
+    if (sd->n_textures && !sd->textures) {
+        c->err = "n_textures > 0 but textures is null";
+        return RT_ERR_ARG;
+    }
+    for (uint32_t t = 0; t < sd->n_textures; ++t)
+        if (!sd->textures[t].rgba8 || sd->textures[t].width < 1 || sd->textures[t].height < 1 || sd->textures[t].width > 32768 ||
+            sd->textures[t].height > 32768) {
+            c->err = "texture needs texels and a size of 1..32768 in each direction";
+            return RT_ERR_ARG;
+        }
+    for (uint32_t m = 0; m < sd->n_models; ++m)
+        if (sd->materials[m].texture < -1 || sd->materials[m].texture >= (int32_t)sd->n_textures) {
+            c->err = "material texture index out of range";
+            return RT_ERR_ARG;
+        }
     const uint32_t T = sd->n_indices / 3;
     for (uint32_t i = 0; i < sd->n_indices; ++i)
         if (sd->indices[i] >= sd->n_vertices) {
@@ -508,6 +532,53 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
                                   sd->materials[m].diffuse_color[2], sd->materials[m].roughness);
         if ((r = dev_upload(c, &c->d_materials, mats.data(), mats.size()))) return r;
     }
+    // ---- diffuse maps: mip chains by 2x2 box average in integers, (a+b+c+d+2)>>2,
+    // level sizes max(1, w>>1); all levels of all maps in one texel buffer
+    c->n_textures = sd->n_textures;
+    if (sd->n_textures) {
+        std::vector<int32_t> mt(sd->n_models);
+        for (uint32_t m = 0; m < sd->n_models; ++m) mt[m] = sd->materials[m].texture;
+        std::vector<DevTexture> tex(sd->n_textures);
+        std::vector<TexLevel> levels;
+        std::vector<uchar4> texels;
+        for (uint32_t t = 0; t < sd->n_textures; ++t) {
+            int w = sd->textures[t].width, h = sd->textures[t].height;
+            tex[t].first_level = (int32_t)levels.size();
+            size_t prev = texels.size();
+            levels.push_back({(uint32_t)prev, w, h});
+            const uchar4* src0 = reinterpret_cast<const uchar4*>(sd->textures[t].rgba8);
+            texels.insert(texels.end(), src0, src0 + (size_t)w * h);
+            while (w > 1 || h > 1) {
+                const int nw = std::max(1, w >> 1), nh = std::max(1, h >> 1);
+                const size_t dst = texels.size();
+                texels.resize(dst + (size_t)nw * nh);
+                for (int y = 0; y < nh; ++y)
+                    for (int x = 0; x < nw; ++x) {
+                        const int x0 = std::min(2 * x, w - 1), x1 = std::min(2 * x + 1, w - 1);
+                        const int y0 = std::min(2 * y, h - 1), y1 = std::min(2 * y + 1, h - 1);
+                        const uchar4 a = texels[prev + (size_t)y0 * w + x0], b = texels[prev + (size_t)y0 * w + x1];
+                        const uchar4 cc = texels[prev + (size_t)y1 * w + x0], d = texels[prev + (size_t)y1 * w + x1];
+                        uchar4 o;
+                        o.x = (unsigned char)((a.x + b.x + cc.x + d.x + 2) >> 2);
+                        o.y = (unsigned char)((a.y + b.y + cc.y + d.y + 2) >> 2);
+                        o.z = (unsigned char)((a.z + b.z + cc.z + d.z + 2) >> 2);
+                        o.w = (unsigned char)((a.w + b.w + cc.w + d.w + 2) >> 2);
+                        texels[dst + (size_t)y * nw + x] = o;
+                    }
+                if (texels.size() >= 0xFFFFFFFFull) {
+                    c->err = "textures exceed 2^32 texels";
+                    return RT_ERR_LIMIT;
+                }
+                levels.push_back({(uint32_t)dst, nw, nh});
+                prev = dst; w = nw; h = nh;
+            }
+            tex[t].n_levels = (int32_t)levels.size() - tex[t].first_level;
+        }
+        if ((r = dev_upload(c, &c->d_material_texture, mt.data(), mt.size()))) return r;
+        if ((r = dev_upload(c, &c->d_textures, tex.data(), tex.size()))) return r;
+        if ((r = dev_upload(c, &c->d_tex_levels, levels.data(), levels.size()))) return r;
+        if ((r = dev_upload(c, &c->d_texels, texels.data(), texels.size()))) return r;
+    }
     c->n_lights = (int)sd->n_lights;
     {
         std::vector<DevLight> lights(sd->n_lights);
@@ -532,6 +603,10 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     c->ss.materials = c->d_materials;
     c->ss.lights = c->d_lights;
     c->ss.n_lights = c->n_lights;
+    c->ss.material_texture = c->d_material_texture;
+    c->ss.textures = c->d_textures;   // null without diffuse maps
+    c->ss.tex_levels = c->d_tex_levels;
+    c->ss.texels = c->d_texels;
 
     // ---- film tiles of this rank, slots in 8x8 pixel blocks inside each tile
     const int W = pr->width, H = pr->height, ts = c->tile;
@@ -582,6 +657,11 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     HIP_TRY(c, hipMemset(c->pb.rays, 0, (n ? n : 1) * 6 * sizeof(float)));
     c->pb.slot_pixel = c->d_slot_pixel;
     c->pb.n = (uint32_t)n;
+    if (c->n_textures) {
+        if ((r = dev_alloc(c, &c->d_duv, n))) return r;
+        HIP_TRY(c, hipMemset(c->d_duv, 0, (n ? n : 1) * sizeof(float4)));
+        c->ss.duv = c->d_duv;
+    }
 
     const int D = pr->max_depth, L = c->n_lights;
     c->n_counts = (uint32_t)(D + 1 + D);
@@ -687,6 +767,24 @@ int rt_read_film(rt_ctx* c, float* rgba_out) {
     for (size_t s = 0; s < n; ++s) {
         uint32_t pix = c->h_slot_pixel[s];
         if (pix != 0xFFFFFFFFu) memcpy(rgba_out + (size_t)pix * 4, &slab[s * 4], 4 * sizeof(float));
+    }
+    return RT_OK;
+}
+
+int rt_read_primary_duv(rt_ctx* c, float* duv_out) {
+    if (!c || !duv_out) return RT_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = c->n_slots;
+    memset(duv_out, 0, (size_t)c->params.width * c->params.height * 4 * sizeof(float));
+    if (!c->n_textures || !n) return RT_OK;
+    std::vector<float> duv(n * 4);
+    std::vector<uint32_t> status(n);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(duv.data(), c->d_duv, n * sizeof(float4), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(status.data(), c->pb.status, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t s = 0; s < n; ++s) {
+        uint32_t pix = c->h_slot_pixel[s];
+        if (pix != 0xFFFFFFFFu && status[s] == 1) memcpy(duv_out + (size_t)pix * 4, &duv[s * 4], 4 * sizeof(float));
     }
     return RT_OK;
 }

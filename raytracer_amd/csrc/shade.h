@@ -43,9 +43,25 @@ struct PathBuffers {
     uint32_t n;         // slots
 };
 
+// One mip level of a diffuse map inside the shared texel buffer.
+struct TexLevel {
+    uint32_t offset;   // first texel
+    int32_t w, h;
+};
+// RGBA8 diffuse map (the reference's spImage4b, src/scene/Material.hpp:61):
+// levels first_level .. first_level + n_levels - 1 of the level table.
+struct DevTexture {
+    int32_t first_level, n_levels;
+};
+
 struct ShadeScene {
     const float* tri_attr;      // 36 floats per triangle: 3 x (normal3 uv2 tangent3 binormal3), 3 pad
     const float4* materials;    // per model: rgb, roughness
+    const int32_t* material_texture;  // per model: texture index or -1
+    const DevTexture* textures;       // null when the scene has no diffuse maps
+    const TexLevel* tex_levels;
+    const uchar4* texels;
+    const float4* duv;          // per slot: dUVx.xy, dUVy.xy of the primary hit, in film pixels (textured scenes only)
     const DevLight* lights;
     int32_t n_lights;
     int32_t have_frame;
@@ -235,6 +251,60 @@ RT_DEV f3 filter_linear(const float4* img, int W, int H, f2 uv) {
     return top * (1.0f - fy) + bot * fy;
 }
 
+// ------------------------------------------------------------ diffuse maps
+// Bilinear fetch of one RGBA8 mip level, channels in 0..255 (repeat wrap,
+// texel centres at +0.5).
+RT_DEV f3 tex_bilinear(const ShadeScene& sc, const TexLevel lv, f2 uv) {
+    const int W = lv.w, H = lv.h;
+    const uchar4* img = sc.texels + lv.offset;
+    float x = uv.x * (float)W - 0.5f, y = uv.y * (float)H - 0.5f;
+    float fx0 = floorf(x), fy0 = floorf(y);
+    float fx = x - fx0, fy = y - fy0;
+    int x0 = (int)fx0, y0 = (int)fy0;
+    int xa = x0 % W; if (xa < 0) xa += W;
+    int xb = (x0 + 1) % W; if (xb < 0) xb += W;
+    int ya = y0 % H; if (ya < 0) ya += H;
+    int yb = (y0 + 1) % H; if (yb < 0) yb += H;
+    uchar4 p00 = img[(size_t)ya * W + xa], p10 = img[(size_t)ya * W + xb];
+    uchar4 p01 = img[(size_t)yb * W + xa], p11 = img[(size_t)yb * W + xb];
+    f3 top = mk3((float)p00.x, (float)p00.y, (float)p00.z) * (1.0f - fx) + mk3((float)p10.x, (float)p10.y, (float)p10.z) * fx;
+    f3 bot = mk3((float)p01.x, (float)p01.y, (float)p01.z) * (1.0f - fx) + mk3((float)p11.x, (float)p11.y, (float)p11.z) * fx;
+    return top * (1.0f - fy) + bot * fy;
+}
+// Stands in for filterTrilinear(*tex, uv, dUVx, dUVy) of src/scene/Material.cpp:198
+// (the filter itself lives in the absent Mango library): lod = log2 of the
+// longer footprint axis in level-0 texels, two bilinear fetches blended.
+RT_DEV f3 tex_trilinear(const ShadeScene& sc, const DevTexture t, f2 uv, float4 duv) {
+    const TexLevel l0v = sc.tex_levels[t.first_level];
+    const float W = (float)l0v.w, H = (float)l0v.h;
+    float ax = duv.x * W, ay = duv.y * H, bx = duv.z * W, by = duv.w * H;
+    float lx = sqrtf(ax * ax + ay * ay), ly = sqrtf(bx * bx + by * by);
+    float rho = (lx < ly) ? ly : lx;
+    const int last = t.n_levels - 1;
+    float lod = 0.0f;
+    if (rho > 1.0f) lod = log2f(rho);
+    if (!(lod < (float)last)) lod = (float)last;
+    int l0 = (int)floorf(lod);
+    int l1 = min(l0 + 1, last);
+    float f = lod - (float)l0;
+    return tex_bilinear(sc, sc.tex_levels[t.first_level + l0], uv) * (1.0f - f) +
+           tex_bilinear(sc, sc.tex_levels[t.first_level + l1], uv) * f;
+}
+RT_DEV f2 fract2(f2 v) { f2 r; r.x = v.x - floorf(v.x); r.y = v.y - floorf(v.y); return r; }
+
+// UV of a hit: the uv part of BVH::postIntersect (src/scene/BVH.cpp:172-187)
+RT_DEV f2 hit_uv(const float* tri_attr, int32_t id1, float hu, float hv) {
+    const float* at = tri_attr + (size_t)(id1 / 3) * 36;
+    float bc[3] = {1.0f - hu - hv, hu, hv};
+    f2 uv; uv.x = 0.f; uv.y = 0.f;
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        uv.x = uv.x + at[v * 11 + 3] * bc[v];
+        uv.y = uv.y + at[v * 11 + 4] * bc[v];
+    }
+    return uv;
+}
+
 // ----------------------------------------------------------------- lights
 // src/lights/PointLight.cpp:14-18, src/lights/EnvLight.cpp:28-43
 RT_DEV f3 light_sample(const DevLight& l, f3 p, f2 u, f3& in, float& pdf) {
@@ -313,6 +383,79 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(PathBuffers pb, CameraK c
     pb.rays[3 * n + s] = d.x; pb.rays[4 * n + s] = d.y; pb.rays[5 * n + s] = d.z;
 }
 
+// UV differences of the primary hits, PASS 1/PASS 2 of
+// src/cpu/PathTracer.cpp:31-90: the film is walked in 2x2 pixel quads, tile by
+// tile; a pixel's dUVx is the difference of the two hits of its quad row,
+// dUVy of its quad column, scaled by the film size.  The reference keeps the
+// four hit vertices in a block that lives for the whole tile and is only
+// overwritten by pixels that hit, so a neighbour that missed (or lies outside
+// the film) contributes the UV of the last earlier quad of the tile (in scan
+// order) whose pixel at that quad position did hit -- zero if there is none.
+// One workgroup per tile: every thread owns a contiguous run of quads,
+// finds the last hit per quad position in its run, the runs are chained
+// through LDS, then each thread replays its run with the carried UVs.
+__global__ __launch_bounds__(RT_BLOCK) void k_quad_duv(PathBuffers pb, const float* __restrict__ tri_attr, float4* __restrict__ duv, int tile,
+                                                       float film_w, float film_h) {
+    __shared__ int32_t s_last[4][RT_BLOCK];
+    const uint32_t tid = threadIdx.x;
+    const int qpr = tile >> 1;                       // quads per tile row
+    const int nq = qpr * qpr;
+    const int per = (nq + RT_BLOCK - 1) / RT_BLOCK;
+    const int q_lo = min((int)tid * per, nq), q_hi = min(q_lo + per, nq);
+    const int bpr = tile >> 3;
+    const uint32_t tile_base = blockIdx.x * (uint32_t)(tile * tile);
+    auto slot_of = [&](int q, int id) -> uint32_t {
+        int x = 2 * (q % qpr) + (id & 1), y = 2 * (q / qpr) + (id >> 1);
+        return tile_base + (uint32_t)((((y >> 3) * bpr + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7));
+    };
+    auto valid_of = [&](uint32_t s) -> bool { return pb.slot_pixel[s] != 0xFFFFFFFFu && pb.hit_id1[s] >= 0; };
+    int32_t last[4] = {-1, -1, -1, -1};
+    for (int q = q_lo; q < q_hi; ++q)
+#pragma unroll
+        for (int id = 0; id < 4; ++id)
+            if (valid_of(slot_of(q, id))) last[id] = q;
+#pragma unroll
+    for (int id = 0; id < 4; ++id) s_last[id][tid] = last[id];
+    __syncthreads();
+    // inclusive max-scan over the threads' runs (quad indices grow with tid)
+    for (uint32_t off = 1; off < RT_BLOCK; off <<= 1) {
+        int32_t v[4];
+#pragma unroll
+        for (int id = 0; id < 4; ++id) v[id] = (tid >= off) ? max(s_last[id][tid], s_last[id][tid - off]) : s_last[id][tid];
+        __syncthreads();
+#pragma unroll
+        for (int id = 0; id < 4; ++id) s_last[id][tid] = v[id];
+        __syncthreads();
+    }
+    f2 cur[4];
+#pragma unroll
+    for (int id = 0; id < 4; ++id) {
+        cur[id].x = 0.f; cur[id].y = 0.f;
+        int32_t ql = tid ? s_last[id][tid - 1] : -1;
+        if (ql >= 0) {
+            uint32_t s = slot_of(ql, id);
+            cur[id] = hit_uv(tri_attr, pb.hit_id1[s], pb.hit_u[s], pb.hit_v[s]);
+        }
+    }
+    for (int q = q_lo; q < q_hi; ++q) {
+        bool ok[4];
+#pragma unroll
+        for (int id = 0; id < 4; ++id) {
+            uint32_t s = slot_of(q, id);
+            ok[id] = valid_of(s);
+            if (ok[id]) cur[id] = hit_uv(tri_attr, pb.hit_id1[s], pb.hit_u[s], pb.hit_v[s]);
+        }
+#pragma unroll
+        for (int id = 0; id < 4; ++id) {
+            if (!ok[id]) continue;
+            const int yB = id >> 1, xB = id & 1;
+            float dxx = cur[yB * 2 + 1].x - cur[yB * 2].x, dxy = cur[yB * 2 + 1].y - cur[yB * 2].y;
+            float dyx = cur[2 + xB].x - cur[xB].x, dyy = cur[2 + xB].y - cur[xB].y;
+            duv[slot_of(q, id)] = make_float4(dxx * film_w, dxy * film_h, dyx * film_w, dyy * film_h);
+        }
+    }
+}
+
 // Shadow rays of one bounce, all lights in one queue: entry k names the path
 // slot and the light, and carries the ray direction (the origin is the
 // path's shaded vertex).  What the ray would add is kept per (light, slot):
@@ -379,10 +522,13 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
             vpos = org + dir * t;
             const float* at = sc.tri_attr + (size_t)(id1 / 3) * 36;
             f3 nrm = mk3(0.f, 0.f, 0.f), tan = mk3(0.f, 0.f, 0.f), bin = mk3(0.f, 0.f, 0.f);
+            f2 uv; uv.x = 0.f; uv.y = 0.f;
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
                 const float* a = at + v * 11;
                 nrm = nrm + mk3(a[0], a[1], a[2]) * bc[v];
+                uv.x = uv.x + a[3] * bc[v];
+                uv.y = uv.y + a[4] * bc[v];
                 tan = tan + mk3(a[5], a[6], a[7]) * bc[v];
                 bin = bin + mk3(a[8], a[9], a[10]) * bc[v];
             }
@@ -403,7 +549,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
             }
             vn = nrm;
             float4 m = sc.materials[id0];
-            f3 col = mk3(255.0f, 255.0f, 255.0f) / 255.0f;
+            // Material::computeBSDF: trilinear with the quad's UV differences at
+            // the primary hit (src/scene/Material.cpp:195-212), bilinear level 0
+            // afterwards (:214-225)
+            f3 col = mk3(255.0f, 255.0f, 255.0f);
+            if (sc.textures) {
+                int32_t ti = sc.material_texture[id0];
+                if (ti >= 0) {
+                    const DevTexture tx = sc.textures[ti];
+                    f2 ruv = fract2(uv);
+                    col = (depth == 0) ? tex_trilinear(sc, tx, ruv, sc.duv[s]) : tex_bilinear(sc, sc.tex_levels[tx.first_level], ruv);
+                }
+            }
+            col = col / 255.0f;
             col = col * mk3(m.x, m.y, m.z);
             bsdf.t = tan; bsdf.b = bin; bsdf.n = nrm;
             bsdf.lobe = make_diffuse(col, m.w);

@@ -50,6 +50,14 @@ class Scene:
     lights: List[Light]
     camera: Camera
     name: str = ""
+    textures: List[np.ndarray] = field(default_factory=list)   # each (H, W, 4) u8, level 0 only
+    material_texture: Optional[np.ndarray] = None              # (M,) i32 texture index per model, -1 = none
+
+    def __post_init__(self):
+        if self.material_texture is None:
+            self.material_texture = np.full(self.materials.shape[0], -1, np.int32)
+        self.material_texture = np.ascontiguousarray(self.material_texture, np.int32)
+        self.textures = [np.ascontiguousarray(t, np.uint8) for t in self.textures]
 
     @property
     def n_triangles(self) -> int:
@@ -343,6 +351,57 @@ def bistro_class(blocks=(4, 3), detail: float = 1.1, n_point_lights: int = 64, e
     lights.append(Light(LIGHT_ENV, intensity=np.array([5.0, 5.0, 5.0], np.float32), env=sky_env(*env_size)))
     cam = make_camera((-16.5, 3.2, 1.3), (1.0, 0.05, 0.35))
     return b.finish(lights, cam, f"bistro_class(blocks={blocks},detail={detail})", jitter=2e-4, seed=2)
+
+
+# --------------------------------------------------------------- textures
+def checker_texture(size=64, cells=8, a=(235, 235, 235), b=(40, 40, 40)) -> np.ndarray:
+    y, x = np.mgrid[0:size, 0:size]
+    m = (((x * cells) // size + (y * cells) // size) & 1).astype(bool)
+    img = np.where(m[..., None], np.array(a, np.uint8), np.array(b, np.uint8)).astype(np.uint8)
+    return np.concatenate([img, np.full((size, size, 1), 255, np.uint8)], -1)
+
+
+def brick_texture(width=128, height=64, seed=11) -> np.ndarray:
+    """Running-bond bricks with mortar lines and per-brick tint; not square on purpose."""
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:height, 0:width]
+    row = y // 8
+    xs = (x + (row & 1) * 8) % width
+    col = xs // 16
+    mortar = ((y % 8) == 0) | ((xs % 16) == 0)
+    tint = rng.integers(-25, 25, (height // 8 + 1, width // 16 + 1))
+    base = np.stack([170 + tint[row, col], 80 + tint[row, col] // 2, 60 + tint[row, col] // 3], -1)
+    img = np.where(mortar[..., None], np.array([200, 196, 188]), base)
+    noise = rng.integers(-8, 9, (height, width, 1))
+    img = np.clip(img + noise, 0, 255).astype(np.uint8)
+    return np.concatenate([img, np.full((height, width, 1), 255, np.uint8)], -1)
+
+
+def noise_texture(size=256, seed=5) -> np.ndarray:
+    """Sum of a few octaves of value noise in three decorrelated channels."""
+    rng = np.random.default_rng(seed)
+    img = np.zeros((size, size, 3))
+    for o, amp in ((4, 0.5), (16, 0.3), (64, 0.2)):
+        g = rng.uniform(0, 1, (o, o, 3))
+        img += amp * np.kron(g, np.ones((size // o, size // o, 1)))
+    img = np.clip(40 + img * 215, 0, 255).astype(np.uint8)
+    return np.concatenate([img, np.full((size, size, 1), 255, np.uint8)], -1)
+
+
+def with_textures(scene: Scene, uv_scale: float = 1.0, every: int = 1) -> Scene:
+    """The same geometry with procedural diffuse maps bound to every `every`-th
+    model (checker, bricks, noise in turn) and UVs scaled so that they repeat."""
+    tex = [checker_texture(), brick_texture(), noise_texture()]
+    mt = np.full(scene.n_models, -1, np.int32)
+    k = 0
+    for m in range(0, scene.n_models, every):
+        mt[m] = k % len(tex)
+        k += 1
+    s = Scene(**{f: getattr(scene, f) for f in ("pos", "normal", "tangent", "binormal", "indices", "tri_model",
+                                                "materials", "lights", "camera")},
+              uv=np.ascontiguousarray(scene.uv * np.float32(uv_scale), np.float32),
+              name=scene.name + "+tex", textures=tex, material_texture=mt)
+    return s
 
 
 # --------------------------------------------------------------- ray sets

@@ -18,8 +18,23 @@ from raytracer_amd import scenes  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+def textured():
+    # 4. textured Cornell box with a sky, 30x26 film in 16-pixel tiles (ragged
+    # tiles, quads with missing neighbours), depth 3, 2 passes
+    s = scenes.with_textures(scenes.cornell_box(env=True), uv_scale=3.0)
+    o = ob.OracleScene(s)
+    film, cnt = o.render(s.camera, 30, 26, 3, 5, 2, threads=1, tile_size=16)
+    lv = [o.texture_level(1, k) for k in range(o.texture_levels(1))]
+    tri = np.array([o.texture_trilinear(2, 0.3, 0.7, (d, 0.0), (0.0, d * 0.5)) for d in (0.0, 0.004, 0.01, 0.1, 10.0)], np.float32)
+    np.savez_compressed(os.path.join(HERE, "cornell_tex_30x26.npz"), film=film, closest=np.uint64(cnt["closest"]),
+                        shadow=np.uint64(cnt["shadow"]), brick_l3=lv[3], brick_last=lv[-1], n_levels=np.int64(len(lv)), tri=tri)
+
+
 def main():
     L = ob.lib()
+    if "--only-textured" in sys.argv:
+        textured()
+        return
     # 1. Cornell box, 32x32: primary hits and a 2-pass film (seed 0, depth 4)
     s = scenes.cornell_box(env=True)
     o = ob.OracleScene(s)
@@ -45,6 +60,7 @@ def main():
     np.savez_compressed(os.path.join(HERE, "atrium_d02.npz"), n_tris=np.int64(a.n_triangles), left=left, right=right, tri=tri,
                         box_sum=boxes.astype(np.float64).sum(0), t=ta, id0=a0, id1=a1, u=ua, v=va,
                         n_inner=np.uint64(c["n_inner"]), n_tri=np.uint64(c["n_tri"]))
+    textured()
     print("golden vectors written to", HERE)
 
 
