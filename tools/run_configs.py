@@ -91,6 +91,17 @@ def main():
                                                "cpu_oracle_240x136_1spp": c, "agreement_240x136": agree(fs, rs),
                                                "finite": bool(np.isfinite(film).all())}
         print("c5", json.dumps(out["c5_bistro_1080p_d12_65lights"]), flush=True)
+    if "tex" in which:
+        # C3's scene with diffuse maps on every model: cost of k_quad_duv + the filtered fetches
+        sp = scenes.sponza_class()
+        st = scenes.with_textures(sp, uv_scale=8.0)
+        _, g0 = gpu_render(sp, 1920, 1080, 8, 16)
+        film4, g1 = gpu_render(st, 1920, 1080, 8, 16)
+        f2, g2 = gpu_render(st, 480, 270, 8, 2, seed=4)
+        r2, c2 = cpu_render(st, 480, 270, 8, 2, seed=4)
+        out["sponza_textured_1080p_d8"] = {"gpu_untextured_16spp": g0, "gpu_textured_16spp": g1, "cpu_oracle_480x270_2spp": c2,
+                                           "agreement_480x270": agree(f2, r2), "finite": bool(np.isfinite(film4).all())}
+        print("tex", json.dumps(out["sponza_textured_1080p_d8"]), flush=True)
     json.dump(out, open(out_path, "w"), indent=1)
 
 
