@@ -16,7 +16,8 @@ _lib = None
 
 class orc_light_desc(C.Structure):
     _fields_ = [("type", C.c_int32), ("pos", C.c_float * 3), ("intensity", C.c_float * 3),
-                ("env_rgba", C.POINTER(C.c_float)), ("env_w", C.c_int32), ("env_h", C.c_int32)]
+                ("env_rgba", C.POINTER(C.c_float)), ("env_w", C.c_int32), ("env_h", C.c_int32),
+                ("p0", C.c_float * 3), ("p1", C.c_float * 3), ("p2", C.c_float * 3)]
 
 
 class orc_texture_desc(C.Structure):
@@ -38,7 +39,21 @@ def lib():
     u64p = C.POINTER(C.c_uint64)
     L.orc_create.restype = vp
     L.orc_create.argtypes = [C.c_uint32, fp, fp, fp, fp, fp, C.c_uint32, up, ip, C.c_uint32, fp, C.c_uint32,
-                             C.POINTER(orc_light_desc), ip, C.c_uint32, C.POINTER(orc_texture_desc)]
+                             C.POINTER(orc_light_desc), ip, C.c_uint32, C.POINTER(orc_texture_desc), ip]
+    L.orc_occluded_bounded.argtypes = [vp, C.c_uint64, fp, fp, ip]
+    for name in ("orc_erf_inv", "orc_erf_poly"):
+        getattr(L, name).restype = C.c_float
+        getattr(L, name).argtypes = [C.c_float]
+    L.orc_mf_D.restype = L.orc_mf_lambda.restype = L.orc_mf_pdf.restype = C.c_float
+    L.orc_mf_D.argtypes = [C.c_int, C.c_float, C.c_float, fp]
+    L.orc_mf_lambda.argtypes = [C.c_int, C.c_float, C.c_float, fp]
+    L.orc_mf_pdf.argtypes = [C.c_int, C.c_float, C.c_float, fp, fp]
+    L.orc_mf_sample_wh.argtypes = [C.c_int, C.c_float, C.c_float, fp, C.c_float, C.c_float, fp]
+    L.orc_fresnel_conductor.argtypes = [fp, fp, fp, C.c_float, fp]
+    L.orc_bsdf_f_pdf.restype = C.c_float
+    L.orc_bsdf_f_pdf.argtypes = [C.c_int, C.c_float, fp, fp, fp, fp]
+    L.orc_bsdf_sample.restype = C.c_float
+    L.orc_bsdf_sample.argtypes = [C.c_int, C.c_float, fp, fp, C.c_float, C.c_float, fp, fp]
     L.orc_texture_levels.argtypes = [vp, C.c_int]
     L.orc_texture_level.argtypes = [vp, C.c_int, C.c_int, ip, ip, C.POINTER(C.c_uint8)]
     L.orc_texture_bilinear.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float, fp]
@@ -73,6 +88,10 @@ def lib():
     L.orc_rng_u01.restype = C.c_float
     L.orc_rng_u01.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
     L.orc_light_sample.argtypes = [vp, C.c_int, fp, C.c_float, C.c_float, fp, fp, fp]
+    L.orc_light_sample_t.restype = C.c_float
+    L.orc_light_sample_t.argtypes = [vp, C.c_int, fp, C.c_float, C.c_float, fp, fp, fp]
+    L.orc_light_pdf_at.restype = C.c_float
+    L.orc_light_pdf_at.argtypes = [vp, C.c_int, fp, fp]
     L.orc_light_pdf.restype = C.c_float
     L.orc_light_pdf.argtypes = [vp, C.c_int, fp]
     L.orc_light_le.argtypes = [vp, C.c_int, fp, fp]
@@ -110,6 +129,9 @@ class OracleScene:
                 self._keep.append(env)
                 lights[k].env_rgba = _f(env)
                 lights[k].env_h, lights[k].env_w = env.shape[0], env.shape[1]
+            if getattr(l, "tri", None) is not None:
+                for name, pt in zip(("p0", "p1", "p2"), l.tri):
+                    getattr(lights[k], name)[:] = [float(x) for x in pt]
         mats = np.ascontiguousarray(s.materials, np.float32)
         textures = list(getattr(s, "textures", []))
         tex = (orc_texture_desc * max(1, len(textures)))()
@@ -120,10 +142,12 @@ class OracleScene:
             tex[k].rgba = t.ctypes.data_as(C.POINTER(C.c_uint8))
         mt = getattr(s, "material_texture", None)
         mt = np.full(s.n_models, -1, np.int32) if mt is None else np.ascontiguousarray(mt, np.int32)
+        mg = getattr(s, "material_glossy", None)
+        mg = np.zeros(s.n_models, np.int32) if mg is None else np.ascontiguousarray(mg, np.int32)
         self._h = L.orc_create(s.pos.shape[0], _f(s.pos), _f(s.normal), _f(s.uv),
                                _f(s.tangent) if use_frame else None, _f(s.binormal) if use_frame else None,
                                s.indices.size, s.indices.ctypes.data_as(C.POINTER(C.c_uint32)), _i(s.tri_model),
-                               s.n_models, _f(mats), len(s.lights), lights, _i(mt), len(textures), tex)
+                               s.n_models, _f(mats), len(s.lights), lights, _i(mt), len(textures), tex, _i(mg))
         self.scene = s
 
     def __del__(self):
@@ -162,6 +186,13 @@ class OracleScene:
         n = rays.shape[1]
         st = np.empty(n, np.int32)
         self._L.orc_occluded(self._h, n, _f(rays), _i(st), None)
+        return st
+
+    def occluded_bounded(self, rays, tmax):
+        rays = np.ascontiguousarray(rays, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        st = np.empty(rays.shape[1], np.int32)
+        self._L.orc_occluded_bounded(self._h, rays.shape[1], _f(rays), _f(tmax), _i(st))
         return st
 
     def brute_force(self, rays):
@@ -206,6 +237,16 @@ class OracleScene:
         pdf = C.c_float()
         self._L.orc_light_sample(self._h, l, _f(f3(*p)), u0, u1, _f(in3), C.byref(pdf), _f(li3))
         return in3, pdf.value, li3
+
+    def light_sample_t(self, l, p, u0, u1):
+        """(in, pdf, li, tmax): sampleLi with the far bound of its shadow ray."""
+        in3, li3 = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        pdf = C.c_float()
+        t = self._L.orc_light_sample_t(self._h, l, _f(f3(*p)), u0, u1, _f(in3), C.byref(pdf), _f(li3))
+        return in3, pdf.value, li3, t
+
+    def light_pdf_at(self, l, p, d):
+        return self._L.orc_light_pdf_at(self._h, l, _f(f3(*p)), _f(f3(*d)))
 
     def light_pdf(self, l, d):
         return self._L.orc_light_pdf(self._h, l, _f(f3(*d)))

@@ -356,12 +356,16 @@ struct BVH {
         return hit;
     }
     // src/scene/BVH.cpp:35-45,63-127
-    RayHit occluded(const Ray& ray, Counters* c = nullptr) const {
+    // tmax: far bound for shadow rays towards a point on an area light (not
+    // in the reference, whose shadow rays are unbounded: infinity reproduces it).
+    // It takes the place of the never-shrinking hit.dist of the reference loop.
+    RayHit occluded(const Ray& ray, Counters* c = nullptr, float tmax = std::numeric_limits<float>::infinity()) const {
         if (c) c->n_rays++;
         RayHit hit = intersectBBox(ray, nodes[rootId].box);
         if (!hit.status) return hit;
         hit.status = false;
-        hit.dist = std::numeric_limits<float>::infinity();
+        hit.dist = tmax;
+        const bool bounded = tmax < std::numeric_limits<float>::infinity();
         const int MAX_STACK = 128;
         int stack[MAX_STACK];
         int top = 0;
@@ -376,7 +380,7 @@ struct BVH {
                     if (c) c->n_tri++;
                     uint32_t i0 = indices[triId], i1 = indices[triId + 1], i2 = indices[triId + 2];
                     RayHit test = intersectTriangle(ray, vertices[i0].pos, vertices[i1].pos, vertices[i2].pos);
-                    if (test.status && test.dist > 0.0001f) {
+                    if (test.status && test.dist > 0.0001f && (!bounded || test.dist < tmax)) {
                         hit = test;
                         hit.id1 = triId;
                         hit.id0 = curr.model;
@@ -519,40 +523,302 @@ struct Diffuse {
     }
 };
 
-// src/bsdf/BSDF.cpp:7-104 with exactly one lobe (the only configuration
-// src/scene/Material.cpp:195-225 ever builds)
+// ------------------------------------------------------- glossy lobe
+// The reference carries a Torrance-Sparrow lobe (src/bsdf/Microfacet.cpp)
+// that Material::computeBSDF only adds inside a comment
+// (src/scene/Material.cpp:205-209).  It is restated here as an OPTION of a
+// material (glossy = 0 reproduces the reference as shipped), with two
+// corrections without which the lobe cannot be sampled at all: the reflected
+// direction is -out + 2 (out.wh) wh (the reference calls glm::reflect(out, wh),
+// which mirrors an incident vector and lands in the wrong hemisphere,
+// Microfacet.cpp:216), and the slope sampler uses the inverse error function
+// where the reference calls erfc (Microfacet.cpp:57,76).  GGX has no
+// counterpart in the reference: it is the Trowbridge-Reitz distribution as
+// published in pbrt-v3 (src/core/microfacet.cpp), from which the reference's
+// Beckmann code descends.
+inline float cos2Theta(vec3 w) { return w.z * w.z; }                       // src/bsdf/BxDF.hpp:39
+inline float tanTheta(vec3 w) { return sinTheta(w) / cosTheta(w); }         // :45
+inline float tan2Theta(vec3 w) { return sin2Theta(w) / cos2Theta(w); }      // :46
+inline float cos2Phi(vec3 w) { return cosPhi(w) * cosPhi(w); }              // :57-59
+inline float sin2Phi(vec3 w) { return sinPhi(w) * sinPhi(w); }              // :60-62
+
+// pbrt-v3 src/core/pbrt.h ErfInv (Giles' single-precision polynomial)
+inline float erfInv(float x) {
+    float w, p;
+    x = clampf(x, -.99999f, .99999f);
+    w = -std::log((1 - x) * (1 + x));
+    if (w < 5) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = 3.43273939e-07f + p * w;
+        p = -3.5233877e-06f + p * w;
+        p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w;
+        p = -0.00125372503f + p * w;
+        p = -0.00417768164f + p * w;
+        p = 0.246640727f + p * w;
+        p = 1.50140941f + p * w;
+    } else {
+        w = std::sqrt(w) - 3;
+        p = -0.000200214257f;
+        p = 0.000100950558f + p * w;
+        p = 0.00134934322f + p * w;
+        p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w;
+        p = -0.0076224613f + p * w;
+        p = 0.00943887047f + p * w;
+        p = 1.00167406f + p * w;
+        p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+// pbrt-v3 src/core/pbrt.h Erf (Abramowitz-Stegun 7.1.26); stands in for the
+// libm erf of Microfacet.cpp:30 so that host and device evaluate the same polynomial
+inline float erfPoly(float x) {
+    const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f;
+    const float p = 0.3275911f;
+    int sign = 1;
+    if (x < 0) sign = -1;
+    x = std::fabs(x);
+    float t = 1 / (1 + p * x);
+    float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
+    return sign * y;
+}
+
+enum GlossyKind { GLOSSY_NONE = 0, GLOSSY_BECKMANN = 1, GLOSSY_GGX = 2 };
+
+// src/bsdf/Microfacet.cpp:7-80 (Beckmann) with erfInv restored
+inline void beckmannSample11(float cosThetaI, float U1, float U2, float* slope_x, float* slope_y) {
+    if ((double)cosThetaI > .9999) {
+        float r = std::sqrt(-std::log(1.0f - U1));
+        float sinPhi = std::sin(2 * (float)M_PI * U2);
+        float cosPhi = std::cos(2 * (float)M_PI * U2);
+        *slope_x = r * cosPhi;
+        *slope_y = r * sinPhi;
+        return;
+    }
+    float sinThetaI = std::sqrt(std::max((float)0, (float)1 - cosThetaI * cosThetaI));
+    float tanThetaI = sinThetaI / cosThetaI;
+    float cotThetaI = 1 / tanThetaI;
+    float a = -1, c = erfPoly(cotThetaI);
+    float sample_x = std::max(U1, (float)1e-6f);
+    float thetaI = std::acos(cosThetaI);
+    float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+    float b = c - (1 + c) * std::pow(1 - sample_x, fit);
+    const float SQRT_PI_INV = 1.f / std::sqrt((float)M_PI);
+    float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * std::exp(-cotThetaI * cotThetaI));
+    int it = 0;
+    while (++it < 10) {
+        if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+        float invErf = erfInv(b);
+        float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * std::exp(-invErf * invErf)) - sample_x;
+        float derivative = normalization * (1 - invErf * tanThetaI);
+        if (std::fabs(value) < 1e-5f) break;
+        if (value > 0)
+            c = b;
+        else
+            a = b;
+        b -= value / derivative;
+    }
+    *slope_x = erfInv(b);
+    *slope_y = erfInv(2.0f * std::max(U2, (float)1e-6f) - 1.0f);
+}
+// pbrt-v3 src/core/microfacet.cpp TrowbridgeReitzSample11
+inline void ggxSample11(float cosTheta, float U1, float U2, float* slope_x, float* slope_y) {
+    if ((double)cosTheta > .9999) {
+        float r = std::sqrt(U1 / (1 - U1));
+        float phi = 6.28318530718f * U2;
+        *slope_x = r * std::cos(phi);
+        *slope_y = r * std::sin(phi);
+        return;
+    }
+    float sinTheta = std::sqrt(std::max((float)0, (float)1 - cosTheta * cosTheta));
+    float tanTheta = sinTheta / cosTheta;
+    float a = 1 / tanTheta;
+    float G1 = 2 / (1 + std::sqrt(1.f + 1.f / (a * a)));
+    float A = 2 * U1 / G1 - 1;
+    float tmp = 1.f / (A * A - 1.f);
+    if (tmp > 1e10f) tmp = 1e10f;
+    float B = tanTheta;
+    float D = std::sqrt(std::max(float(B * B * tmp * tmp - (A * A - B * B) * tmp), float(0)));
+    float slope_x_1 = B * tmp - D;
+    float slope_x_2 = B * tmp + D;
+    *slope_x = (A < 0 || slope_x_2 > 1.f / tanTheta) ? slope_x_1 : slope_x_2;
+    float S;
+    if (U2 > 0.5f) {
+        S = 1.f;
+        U2 = 2.f * (U2 - .5f);
+    } else {
+        S = -1.f;
+        U2 = 2.f * (.5f - U2);
+    }
+    float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) /
+              (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+    *slope_y = S * z * std::sqrt(1.f + *slope_x * *slope_x);
+}
+
+// MicrofacetDistribution with visible-area sampling (src/bsdf/Microfacet.hpp:9-50)
+struct Microfacet {
+    int kind = GLOSSY_BECKMANN;
+    float alphax = 0.5f, alphay = 0.6f;
+    // src/bsdf/Microfacet.cpp:108-115 / pbrt-v3 TrowbridgeReitzDistribution::D
+    float D(vec3 wh) const {
+        float t2 = tan2Theta(wh);
+        if (std::isinf(t2)) return 0.f;
+        float cos4Theta = cos2Theta(wh) * cos2Theta(wh);
+        if (kind == GLOSSY_BECKMANN)
+            return std::exp(-t2 * (cos2Phi(wh) / (alphax * alphax) + sin2Phi(wh) / (alphay * alphay))) /
+                   ((float)M_PI * alphax * alphay * cos4Theta);
+        float e = (cos2Phi(wh) / (alphax * alphax) + sin2Phi(wh) / (alphay * alphay)) * t2;
+        return 1 / ((float)M_PI * alphax * alphay * cos4Theta * (1 + e) * (1 + e));
+    }
+    // src/bsdf/Microfacet.cpp:117-126 / pbrt-v3 TrowbridgeReitzDistribution::Lambda
+    float lambda(vec3 w) const {
+        float absTanTheta = std::fabs(tanTheta(w));
+        if (std::isinf(absTanTheta)) return 0.f;
+        float alpha = std::sqrt(cos2Phi(w) * alphax * alphax + sin2Phi(w) * alphay * alphay);
+        if (kind == GLOSSY_BECKMANN) {
+            float a = 1 / (alpha * absTanTheta);
+            if (a >= 1.6f) return 0;
+            return (1 - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
+        }
+        float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
+        return (-1 + std::sqrt(1.f + alpha2Tan2Theta)) / 2;
+    }
+    float G1(vec3 w) const { return 1 / (1 + lambda(w)); }                       // Microfacet.hpp:14-17
+    float G(vec3 wo, vec3 wi) const { return 1 / (1 + lambda(wo) + lambda(wi)); }  // :18-20
+    // src/bsdf/Microfacet.cpp:82-103,158-165 (stretch, sample slopes, rotate, unstretch)
+    vec3 sampleWh(vec3 wo, vec2 u) const {
+        bool flip = wo.z < 0;
+        vec3 wi = flip ? -wo : wo;
+        vec3 wiStretched = normalize(vec3{alphax * wi.x, alphay * wi.y, wi.z});
+        float slope_x, slope_y;
+        if (kind == GLOSSY_BECKMANN)
+            beckmannSample11(cosTheta(wiStretched), u.x, u.y, &slope_x, &slope_y);
+        else
+            ggxSample11(cosTheta(wiStretched), u.x, u.y, &slope_x, &slope_y);
+        float tmp = cosPhi(wiStretched) * slope_x - sinPhi(wiStretched) * slope_y;
+        slope_y = sinPhi(wiStretched) * slope_x + cosPhi(wiStretched) * slope_y;
+        slope_x = tmp;
+        slope_x = alphax * slope_x;
+        slope_y = alphay * slope_y;
+        vec3 wh = normalize(vec3{-slope_x, -slope_y, 1.f});
+        if (flip) wh = -wh;
+        return wh;
+    }
+    // src/bsdf/Microfacet.cpp:168-174 with sampleVisibleArea = true (Microfacet.hpp:40)
+    float pdf(vec3 wo, vec3 wh) const { return D(wh) * G1(wo) * std::fabs(dot(wo, wh)) / absCosTheta(wo); }
+};
+
+// src/bsdf/Microfacet.cpp:176-198
+struct FresnelConductor {
+    vec3 etaI{0.5f, 0.5f, 0.5f}, etaT{0.5f, 0.5f, 0.5f}, k{0, 0, 0};
+    vec3 eval(float cosI) const {
+        float cosThetaI = clampf(cosI, -1, 1);
+        vec3 eta = etaT / etaI;
+        vec3 etak = k / etaI;
+        float cosThetaI2 = cosThetaI * cosThetaI;
+        float sinThetaI2 = 1.f - cosThetaI2;
+        vec3 eta2 = eta * eta;
+        vec3 etak2 = etak * etak;
+        auto sq = [](vec3 v) { return vec3{std::sqrt(v.x), std::sqrt(v.y), std::sqrt(v.z)}; };
+        vec3 t0 = eta2 - etak2 - V3(sinThetaI2);
+        vec3 a2plusb2 = sq(t0 * t0 + 4.f * eta2 * etak2);
+        vec3 t1 = a2plusb2 + V3(cosThetaI2);
+        vec3 a = sq(0.5f * (a2plusb2 + t0));
+        vec3 t2 = 2.f * cosThetaI * a;
+        vec3 Rs = (t1 - t2) / (t1 + t2);
+        vec3 t3 = cosThetaI2 * a2plusb2 + V3(sinThetaI2 * sinThetaI2);
+        vec3 t4 = t2 * sinThetaI2;
+        vec3 Rp = Rs * (t3 - t4) / (t3 + t4);
+        return 0.5f * (Rp + Rs);
+    }
+};
+
+// src/bsdf/Microfacet.cpp:200-228
+struct Reflection {
+    vec3 R{1, 1, 1};
+    Microfacet distribution;
+    FresnelConductor fresnel;
+    vec3 f(vec3 wo, vec3 wi) const {
+        float cosThetaO = absCosTheta(wo), cosThetaI = absCosTheta(wi);
+        vec3 wh = wi + wo;
+        if (cosThetaI == 0 || cosThetaO == 0) return {0.f, 0.f, 0.f};
+        if (wh.x == 0 && wh.y == 0 && wh.z == 0) return {0.f, 0.f, 0.f};
+        wh = normalize(wh);
+        vec3 F = fresnel.eval(dot(wi, wh));
+        return R * distribution.D(wh) * distribution.G(wo, wi) * F / (4 * cosThetaI * cosThetaO);
+    }
+    // pdf is left untouched on the two early returns, as in the reference
+    vec3 sampled(vec3 out, vec2 u, vec3& in, float& pdf) const {
+        if (out.z == 0) return {0.f, 0.f, 0.f};
+        vec3 wh = distribution.sampleWh(out, u);
+        in = -out + 2.f * dot(out, wh) * wh;   // corrected, see the note above
+        if (!sameHemisphere(out, in)) return {0.f, 0.f, 0.f};
+        pdf = distribution.pdf(out, wh) / (4.f * dot(out, wh));
+        return f(out, in);
+    }
+    float pdf(vec3 wo, vec3 wi) const {
+        if (!sameHemisphere(wo, wi)) return 0;
+        vec3 wh = normalize(wo + wi);
+        return distribution.pdf(wo, wh) / (4.f * dot(wo, wh));
+    }
+};
+
+// src/bsdf/BSDF.cpp:7-104 for the lobe sets src/scene/Material.cpp:195-225
+// can build: the Diffuse lobe, plus the Reflection lobe when the material asks
+// for it.  Both are REFLECTION lobes matched by the ALL flags.
 struct BSDF {
     vec3 t, b, n;
     Diffuse lobe;
+    Reflection glossy;
+    int numParts = 1;
     BSDF() = default;
     BSDF(const Vertex& v, const Diffuse& d) : t(v.tangent), b(v.binormal), n(v.normal), lobe(d) {}
+    void add(const Reflection& r) { glossy = r; numParts = 2; }
     vec3 world2local(vec3 v) const { return {dot(t, v), dot(b, v), dot(n, v)}; }
     vec3 local2world(vec3 v) const {
         return {t.x * v.x + b.x * v.y + n.x * v.z, t.y * v.x + b.y * v.y + n.y * v.z,
                 t.z * v.x + b.z * v.y + n.z * v.z};
     }
+    // :36-48
     vec3 f(vec3 outW, vec3 inW) const {
         vec3 in = world2local(inW), out = world2local(outW);
         bool reflect = dot(inW, n) * dot(outW, n) > 0;
         vec3 r{0.f, 0.f, 0.f};
         if (reflect) r = r + lobe.f(out, in);
+        if (reflect && numParts > 1) r = r + glossy.f(out, in);
         return r;
     }
+    // :91-104
     float pdf(vec3 outW, vec3 inW) const {
         vec3 out = world2local(outW), in = world2local(inW);
         float p = 0.f;
         p += lobe.pdf(out, in);
-        p /= 1.0f;
+        if (numParts > 1) p += glossy.pdf(out, in);
+        p /= (float)numParts;
         return p;
     }
+    // :50-89
     vec3 sample(vec3 outW, vec2 u, vec3& inW, float& p) const {
+        const int matchingComps = numParts;
         p = 0.f;
-        int comp = std::min((int)std::floor(u.x * 1), 0);
-        vec2 uR = {u.x * 1 - comp, u.y};
+        int comp = std::min((int)std::floor(u.x * matchingComps), matchingComps - 1);
+        vec2 uR = {u.x * matchingComps - comp, u.y};
         vec3 wi, wo = world2local(outW);
-        vec3 fr = lobe.sampled(wo, uR, wi, p);
+        vec3 fr = comp == 0 ? lobe.sampled(wo, uR, wi, p) : glossy.sampled(wo, uR, wi, p);
         if (p == 0) return {0.f, 0.f, 0.f};
         inW = local2world(wi);
+        if (matchingComps > 1) {
+            p += comp == 0 ? glossy.pdf(wo, wi) : lobe.pdf(wo, wi);
+            p /= matchingComps;
+            bool reflect = dot(inW, n) * dot(outW, n) > 0;
+            fr = {0.f, 0.f, 0.f};
+            if (reflect) {
+                fr = fr + lobe.f(wo, wi);
+                fr = fr + glossy.f(wo, wi);
+            }
+        }
         return fr;
     }
 };
@@ -634,7 +900,7 @@ inline vec3 filterLinear(const float* img, int W, int H, vec2 uv) {
     return top * (1.0f - fy) + bot * fy;
 }
 
-enum LightType { LIGHT_POINT = 0, LIGHT_ENV = 3 };  // src/lights/LightSource.hpp:12-17
+enum LightType { LIGHT_POINT = 0, LIGHT_AREA = 2, LIGHT_ENV = 3 };  // src/lights/LightSource.hpp:12-17
 
 struct Light {
     int type = LIGHT_POINT;
@@ -643,8 +909,21 @@ struct Light {
     std::vector<float> img;   // env: RGBA32F, row-major, W*H*4
     int W = 0, H = 0;
     Distribution2D dist;
+    // Area: one emissive triangle.  The reference only names the enum value
+    // (src/lights/LightSource.hpp:15); the definition is pbrt-v3's
+    // DiffuseAreaLight over a Triangle behind the LightSource interface:
+    // uniform area sampling, solid-angle pdf dist^2 / (|cos| area), one-sided
+    // emission I on the side of cross(p1-p0, p2-p0), le() = 0 (the reference's
+    // integrator has no emission term at hits).
+    vec3 p0{0, 0, 0}, p1{0, 0, 0}, p2{0, 0, 0}, nrm{0, 0, 1};
+    float area = 0;
 
     bool isDelta() const { return type == LIGHT_POINT; }
+    void buildArea() {
+        vec3 c = cross(p1 - p0, p2 - p0);
+        area = 0.5f * std::sqrt(length2(c));
+        nrm = normalize(c);
+    }
 
     // src/lights/EnvLight.cpp:8-26.  glm::mat3 is filled column-major from
     // the literal, so (M*rgb).y = 0.3575761 r + 0.7151522 g + 0.1191920 b.
@@ -662,11 +941,31 @@ struct Light {
         dist = Distribution2D(table, H, W);
     }
     // src/lights/PointLight.cpp:14-18, src/lights/EnvLight.cpp:28-43
-    vec3 sampleLi(const Vertex& vtx, vec2 u, vec3& in, float& pdf) const {
+    // tmax: where a shadow ray towards the sample must stop (infinity for
+    // the reference's lights, whose shadow rays are unbounded)
+    vec3 sampleLi(const Vertex& vtx, vec2 u, vec3& in, float& pdf, float* tmax = nullptr) const {
+        if (tmax) *tmax = std::numeric_limits<float>::infinity();
         if (type == LIGHT_POINT) {
             in = normalize(pos - vtx.pos);
             pdf = 1.f;
             return I / length2(pos - vtx.pos);
+        }
+        if (type == LIGHT_AREA) {
+            float su0 = std::sqrt(u.x);
+            float b0 = 1.f - su0, b1 = u.y * su0;
+            vec3 p = p0 * b0 + p1 * b1 + p2 * (1.f - b0 - b1);
+            vec3 w = p - vtx.pos;
+            float d2 = length2(w);
+            pdf = 0.0f;
+            in = {0.f, 0.f, 0.f};
+            if (d2 == 0) return {0.f, 0.f, 0.f};
+            float d = std::sqrt(d2);
+            in = w / d;
+            float cosL = dot(nrm, -in);
+            pdf = d2 / (std::fabs(cosL) * area);
+            if (!std::isfinite(pdf)) { pdf = 0.0f; return {0.f, 0.f, 0.f}; }
+            if (tmax) *tmax = d * (1.0f - 1e-4f);
+            return cosL > 0 ? I : vec3{0.f, 0.f, 0.f};
         }
         float mapPdf;
         vec2 uv = dist.sampleContinuous(u, mapPdf);
@@ -681,8 +980,14 @@ struct Light {
         return filterLinear(img.data(), W, H, uv) * I;
     }
     // src/lights/PointLight.cpp:20-22, src/lights/EnvLight.cpp:45-52
-    float pdfLi(const Vertex&, vec3 inW) const {
+    float pdfLi(const Vertex& vtx, vec3 inW) const {
         if (type == LIGHT_POINT) return 1.0f;
+        if (type == LIGHT_AREA) {
+            RayHit h = intersectTriangle(Ray(vtx.pos, inW), p0, p1, p2);
+            if (!h.status || !(h.dist > 0.0001f)) return 0;
+            float p = (h.dist * h.dist) / (std::fabs(dot(nrm, -inW)) * area);
+            return std::isfinite(p) ? p : 0;
+        }
         float theta = sphericalTheta(inW), phi = sphericalPhi(inW);
         float sinT = std::sin(theta);
         if (sinT == 0) return 0;
@@ -690,7 +995,7 @@ struct Light {
     }
     // src/lights/LightSource.hpp:28-30, src/lights/EnvLight.cpp:60-65
     vec3 le(const Ray& ray) const {
-        if (type == LIGHT_POINT) return {0.f, 0.f, 0.f};
+        if (type != LIGHT_ENV) return {0.f, 0.f, 0.f};
         vec3 w = normalize(ray.dir);
         vec2 st = {sphericalPhi(w) * INV_2PI, sphericalTheta(w) * INV_PI};
         return filterLinear(img.data(), W, H, st);
@@ -768,7 +1073,23 @@ struct MaterialData {
     vec3 diffuseColor{1, 1, 1};
     float roughness = 0.5f;  // src/scene/Material.cpp:9
     int texture = -1;        // index into Scene::textures, -1 = none (_diffTexture null)
+    int glossy = GLOSSY_NONE;  // GlossyKind: adds the Reflection lobe of Material.cpp:205-209
 };
+
+// The lobe of the commented block at src/scene/Material.cpp:205-209:
+// FresnelConductor(0.5, 0.5, diffColor), alpha = (roughness, roughness + 0.1), R = 1
+inline void addGlossy(BSDF& bsdf, const MaterialData& m, vec3 diffColor) {
+    if (m.glossy == GLOSSY_NONE) return;
+    Reflection r;
+    r.R = {1.f, 1.f, 1.f};
+    r.fresnel.etaI = {0.5f, 0.5f, 0.5f};
+    r.fresnel.etaT = {0.5f, 0.5f, 0.5f};
+    r.fresnel.k = diffColor;
+    r.distribution.kind = m.glossy;
+    r.distribution.alphax = m.roughness;
+    r.distribution.alphay = m.roughness + 0.1f;
+    bsdf.add(r);
+}
 
 struct Camera {
     vec3 pos, right, up, forward;  // src/cpu/Integrator.cpp:85-92
@@ -814,7 +1135,9 @@ inline BSDF computeBSDF(const Scene& s, const Vertex& v, int model, vec2 dUVx, v
     vec3 c = m.texture >= 0 ? s.textures[m.texture].filterTrilinear(repeatUV, dUVx, dUVy) : V3(255.0f);
     c = c / 255.0f;
     c = c * m.diffuseColor;
-    return BSDF(v, Diffuse(c, m.roughness));
+    BSDF bsdf(v, Diffuse(c, m.roughness));
+    addGlossy(bsdf, m, c);
+    return bsdf;
 }
 // src/scene/Material.cpp:214-225: later bounces use the plain bilinear fetch
 inline BSDF computeBSDF(const Scene& s, const Vertex& v, int model) {
@@ -823,7 +1146,9 @@ inline BSDF computeBSDF(const Scene& s, const Vertex& v, int model) {
     vec3 c = m.texture >= 0 ? s.textures[m.texture].filterLinear(repeatUV) : V3(255.0f);
     c = c / 255.0f;
     c = c * m.diffuseColor;
-    return BSDF(v, Diffuse(c, m.roughness));
+    BSDF bsdf(v, Diffuse(c, m.roughness));
+    addGlossy(bsdf, m, c);   // the reference's comment sits in the first overload only; a material keeps its lobes on every bounce here
+    return bsdf;
 }
 
 // PASS 2 of src/cpu/PathTracer.cpp:70-160 for one pixel whose primary ray
@@ -843,13 +1168,13 @@ inline void shadePixel(const Scene& s, int x, int y, int W, int maxDepth, uint64
         for (int li_ = 0; li_ < L; ++li_) {
             const Light& light = s.lights[li_];
             vec3 in{0.f, 0.f, 0.f};
-            float lightPdf;
+            float lightPdf, tmax;
             vec2 u = {rng_u01(seed, pixel, pass, dim_light(d, L, li_, 0)),
                       rng_u01(seed, pixel, pass, dim_light(d, L, li_, 1))};
-            vec3 li = light.sampleLi(vertex, u, in, lightPdf);
+            vec3 li = light.sampleLi(vertex, u, in, lightPdf, &tmax);
             if (lightPdf == 0.0f) continue;
             nShadow++;
-            RayHit shadowHit = s.bvh.occluded(Ray(vertex.pos, in));
+            RayHit shadowHit = s.bvh.occluded(Ray(vertex.pos, in), nullptr, tmax);
             if (shadowHit.status) continue;
             vec3 bsdfColor = bsdf.f(out, in);
             float bsdfPdf = bsdf.pdf(out, in);

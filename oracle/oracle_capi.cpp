@@ -12,6 +12,7 @@ struct orc_light_desc {
     float intensity[3];     // point intensity / env scale
     const float* env_rgba;  // env: W*H*4 floats
     int32_t env_w, env_h;
+    float p0[3], p1[3], p2[3];  // area (type 2): the emissive triangle, radiance = intensity
 };
 
 struct orc_texture_desc {
@@ -30,7 +31,8 @@ orc_scene* orc_create(uint32_t n_vertices, const float* pos, const float* normal
                       const uint32_t* indices, const int32_t* tri_model, uint32_t n_models,
                       const float* materials /* rgb + roughness per model */, uint32_t n_lights,
                       const orc_light_desc* lights, const int32_t* material_texture /* per model or null */,
-                      uint32_t n_textures, const orc_texture_desc* textures) {
+                      uint32_t n_textures, const orc_texture_desc* textures,
+                      const int32_t* material_glossy /* per model or null: 0 none, 1 Beckmann, 2 GGX */) {
     auto* o = new orc_scene();
     std::vector<Vertex> verts(n_vertices);
     for (uint32_t i = 0; i < n_vertices; ++i) {
@@ -50,6 +52,7 @@ orc_scene* orc_create(uint32_t n_vertices, const float* pos, const float* normal
         o->s.materials[m].diffuseColor = {materials[4 * m], materials[4 * m + 1], materials[4 * m + 2]};
         o->s.materials[m].roughness = materials[4 * m + 3];
         o->s.materials[m].texture = material_texture ? material_texture[m] : -1;
+        o->s.materials[m].glossy = material_glossy ? material_glossy[m] : 0;
     }
     o->s.textures.resize(n_textures);
     for (uint32_t t = 0; t < n_textures; ++t) o->s.textures[t].build(textures[t].rgba, textures[t].width, textures[t].height);
@@ -63,6 +66,12 @@ orc_scene* orc_create(uint32_t n_vertices, const float* pos, const float* normal
             lt.H = lights[l].env_h;
             lt.img.assign(lights[l].env_rgba, lights[l].env_rgba + (size_t)lt.W * lt.H * 4);
             lt.buildEnv();
+        }
+        if (lt.type == LIGHT_AREA) {
+            lt.p0 = {lights[l].p0[0], lights[l].p0[1], lights[l].p0[2]};
+            lt.p1 = {lights[l].p1[0], lights[l].p1[1], lights[l].p1[2]};
+            lt.p2 = {lights[l].p2[0], lights[l].p2[1], lights[l].p2[2]};
+            lt.buildArea();
         }
         o->s.lights.push_back(std::move(lt));
     }
@@ -125,6 +134,16 @@ void orc_occluded(const orc_scene* o, uint64_t n, const float* rays, int32_t* st
         status[i] = o->s.bvh.occluded(r, counters ? &c : nullptr).status ? 1 : 0;
     }
     if (counters) { counters[0] = c.n_inner; counters[1] = c.n_tri; counters[2] = c.n_rays; }
+}
+
+// Any-hit with a far bound per ray (shadow rays towards area lights)
+void orc_occluded_bounded(const orc_scene* o, uint64_t n, const float* rays, const float* tmax, int32_t* status) {
+    const float *ox = rays, *oy = rays + n, *oz = rays + 2 * n, *dx = rays + 3 * n, *dy = rays + 4 * n,
+                *dz = rays + 5 * n;
+    for (uint64_t i = 0; i < n; ++i) {
+        Ray r({ox[i], oy[i], oz[i]}, {dx[i], dy[i], dz[i]});
+        status[i] = o->s.bvh.occluded(r, nullptr, tmax[i]).status ? 1 : 0;
+    }
 }
 
 // Brute force over every triangle with the same triangle test and the same
@@ -248,6 +267,57 @@ float orc_dist2d_pdf(const float* data, int w, int h, float p0, float p1) {
     return d.pdf({p0, p1});
 }
 
+// Glossy-lobe hooks (directions in the shading frame)
+static Microfacet mf_of(int kind, float ax, float ay) {
+    Microfacet m;
+    m.kind = kind; m.alphax = ax; m.alphay = ay;
+    return m;
+}
+float orc_erf_inv(float x) { return erfInv(x); }
+float orc_erf_poly(float x) { return erfPoly(x); }
+float orc_mf_D(int kind, float ax, float ay, const float* wh) { return mf_of(kind, ax, ay).D({wh[0], wh[1], wh[2]}); }
+float orc_mf_lambda(int kind, float ax, float ay, const float* w) { return mf_of(kind, ax, ay).lambda({w[0], w[1], w[2]}); }
+float orc_mf_pdf(int kind, float ax, float ay, const float* wo, const float* wh) {
+    return mf_of(kind, ax, ay).pdf({wo[0], wo[1], wo[2]}, {wh[0], wh[1], wh[2]});
+}
+void orc_mf_sample_wh(int kind, float ax, float ay, const float* wo, float u0, float u1, float* wh) {
+    vec3 h = mf_of(kind, ax, ay).sampleWh({wo[0], wo[1], wo[2]}, {u0, u1});
+    wh[0] = h.x; wh[1] = h.y; wh[2] = h.z;
+}
+void orc_fresnel_conductor(const float* etaI, const float* etaT, const float* k, float cosI, float* out) {
+    FresnelConductor f;
+    f.etaI = {etaI[0], etaI[1], etaI[2]}; f.etaT = {etaT[0], etaT[1], etaT[2]}; f.k = {k[0], k[1], k[2]};
+    vec3 r = f.eval(cosI);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+// The BSDF a material with the given lobe builds, in an identity frame
+static BSDF bsdf_of(int glossy, float roughness, const float* color) {
+    Vertex v;
+    v.tangent = {1, 0, 0}; v.binormal = {0, 1, 0}; v.normal = {0, 0, 1};
+    MaterialData m;
+    m.roughness = roughness; m.glossy = glossy;
+    vec3 c = {color[0], color[1], color[2]};
+    BSDF b(v, Diffuse(c, roughness));
+    addGlossy(b, m, c);
+    return b;
+}
+float orc_bsdf_f_pdf(int glossy, float roughness, const float* color, const float* out, const float* in, float* f3) {
+    BSDF b = bsdf_of(glossy, roughness, color);
+    vec3 o = {out[0], out[1], out[2]}, i = {in[0], in[1], in[2]};
+    vec3 f = b.f(o, i);
+    f3[0] = f.x; f3[1] = f.y; f3[2] = f.z;
+    return b.pdf(o, i);
+}
+float orc_bsdf_sample(int glossy, float roughness, const float* color, const float* out, float u0, float u1, float* in3, float* f3) {
+    BSDF b = bsdf_of(glossy, roughness, color);
+    vec3 in{0, 0, 0};
+    float pdf = 0;
+    vec3 f = b.sample({out[0], out[1], out[2]}, {u0, u1}, in, pdf);
+    in3[0] = in.x; in3[1] = in.y; in3[2] = in.z;
+    f3[0] = f.x; f3[1] = f.y; f3[2] = f.z;
+    return pdf;
+}
+
 // Texture hooks: mip level sizes / texels and the two filters (channels 0..255)
 int orc_texture_levels(const orc_scene* o, int t) { return (int)o->s.textures[t].levels.size(); }
 void orc_texture_level(const orc_scene* o, int t, int level, int32_t* w, int32_t* h, uint8_t* rgba_out) {
@@ -277,6 +347,22 @@ void orc_light_sample(const orc_scene* o, int l, const float* p, float u0, float
     vec3 li = o->s.lights[l].sampleLi(v, {u0, u1}, in, *pdf);
     in3[0] = in.x; in3[1] = in.y; in3[2] = in.z;
     li3[0] = li.x; li3[1] = li.y; li3[2] = li.z;
+}
+// Same with the shadow ray's far bound, and the pdf seen from a given position
+float orc_light_sample_t(const orc_scene* o, int l, const float* p, float u0, float u1, float* in3, float* pdf, float* li3) {
+    Vertex v;
+    v.pos = {p[0], p[1], p[2]};
+    vec3 in{0, 0, 0};
+    float tmax = 0;
+    vec3 li = o->s.lights[l].sampleLi(v, {u0, u1}, in, *pdf, &tmax);
+    in3[0] = in.x; in3[1] = in.y; in3[2] = in.z;
+    li3[0] = li.x; li3[1] = li.y; li3[2] = li.z;
+    return tmax;
+}
+float orc_light_pdf_at(const orc_scene* o, int l, const float* p, const float* in) {
+    Vertex v;
+    v.pos = {p[0], p[1], p[2]};
+    return o->s.lights[l].pdfLi(v, {in[0], in[1], in[2]});
 }
 float orc_light_pdf(const orc_scene* o, int l, const float* in) {
     Vertex v;

@@ -15,7 +15,10 @@ from typing import List, Optional
 import numpy as np
 
 LIGHT_POINT = 0  # src/lights/LightSource.hpp:12-17
+LIGHT_AREA = 2
 LIGHT_ENV = 3
+
+GLOSSY_NONE, GLOSSY_BECKMANN, GLOSSY_GGX = 0, 1, 2
 
 
 @dataclass
@@ -24,6 +27,7 @@ class Light:
     pos: np.ndarray = field(default_factory=lambda: np.zeros(3, np.float32))
     intensity: np.ndarray = field(default_factory=lambda: np.ones(3, np.float32))
     env: Optional[np.ndarray] = None  # (H, W, 4) float32
+    tri: Optional[np.ndarray] = None  # area: (3, 3) float32 corners; emits `intensity` on the side of cross(p1-p0, p2-p0)
 
 
 @dataclass
@@ -52,8 +56,12 @@ class Scene:
     name: str = ""
     textures: List[np.ndarray] = field(default_factory=list)   # each (H, W, 4) u8, level 0 only
     material_texture: Optional[np.ndarray] = None              # (M,) i32 texture index per model, -1 = none
+    material_glossy: Optional[np.ndarray] = None               # (M,) i32: 0 none, 1 Beckmann, 2 GGX lobe
 
     def __post_init__(self):
+        if self.material_glossy is None:
+            self.material_glossy = np.zeros(self.materials.shape[0], np.int32)
+        self.material_glossy = np.ascontiguousarray(self.material_glossy, np.int32)
         if self.material_texture is None:
             self.material_texture = np.full(self.materials.shape[0], -1, np.int32)
         self.material_texture = np.ascontiguousarray(self.material_texture, np.int32)
@@ -402,6 +410,38 @@ def with_textures(scene: Scene, uv_scale: float = 1.0, every: int = 1) -> Scene:
               uv=np.ascontiguousarray(scene.uv * np.float32(uv_scale), np.float32),
               name=scene.name + "+tex", textures=tex, material_texture=mt)
     return s
+
+
+def replace(scene: Scene, **kw) -> Scene:
+    """A copy of the scene with some fields replaced."""
+    f = {k: getattr(scene, k) for k in ("pos", "normal", "uv", "tangent", "binormal", "indices", "tri_model", "materials",
+                                        "lights", "camera", "name", "textures", "material_texture", "material_glossy")}
+    f.update(kw)
+    return Scene(**f)
+
+
+def with_glossy(scene: Scene, kind: int = GLOSSY_GGX, every: int = 1) -> Scene:
+    """The same scene with the microfacet lobe on every `every`-th model."""
+    mg = np.zeros(scene.n_models, np.int32)
+    mg[::every] = kind
+    return replace(scene, material_glossy=mg, name=scene.name + f"+glossy{kind}")
+
+
+def area_quad(p0, p1, p2, p3, radiance) -> List[Light]:
+    """Two emissive triangles (p0,p1,p2), (p0,p2,p3) emitting on the side of cross(p1-p0, p2-p0)."""
+    pts = [np.asarray(p, np.float32) for p in (p0, p1, p2, p3)]
+    rad = np.asarray(radiance, np.float32)
+    return [Light(LIGHT_AREA, intensity=rad, tri=np.stack([pts[0], pts[1], pts[2]])),
+            Light(LIGHT_AREA, intensity=rad, tri=np.stack([pts[0], pts[2], pts[3]]))]
+
+
+def cornell_area(glossy: int = GLOSSY_NONE) -> Scene:
+    """Cornell box lit by a ceiling panel (two area lights just below the
+    ceiling, facing down) instead of the point light."""
+    s = cornell_box()
+    panel = area_quad((-0.3, 1.98, -0.3), (0.3, 1.98, -0.3), (0.3, 1.98, 0.3), (-0.3, 1.98, 0.3), (18.0, 16.0, 12.0))
+    s = replace(s, lights=panel, name="cornell_area")
+    return with_glossy(s, glossy) if glossy else s
 
 
 # --------------------------------------------------------------- ray sets

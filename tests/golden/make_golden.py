@@ -30,10 +30,25 @@ def textured():
                         shadow=np.uint64(cnt["shadow"]), brick_l3=lv[3], brick_last=lv[-1], n_levels=np.int64(len(lv)), tri=tri)
 
 
+def glossy_area():
+    # 5. Cornell box under a ceiling panel (two area lights), microfacet lobe on every model
+    out = {}
+    for key, kind in (("ggx", scenes.GLOSSY_GGX), ("beckmann", scenes.GLOSSY_BECKMANN)):
+        s = scenes.cornell_area(glossy=kind)
+        film, cnt = ob.OracleScene(s).render(s.camera, 24, 24, 3, 2, 2, threads=1)
+        out[key] = film
+        out[key + "_closest"] = np.uint64(cnt["closest"])
+        out[key + "_shadow"] = np.uint64(cnt["shadow"])
+    np.savez_compressed(os.path.join(HERE, "cornell_area_ggx_24.npz"), **out)
+
+
 def main():
     L = ob.lib()
     if "--only-textured" in sys.argv:
         textured()
+        return
+    if "--only-glossy-area" in sys.argv:
+        glossy_area()
         return
     # 1. Cornell box, 32x32: primary hits and a 2-pass film (seed 0, depth 4)
     s = scenes.cornell_box(env=True)
@@ -61,6 +76,7 @@ def main():
                         box_sum=boxes.astype(np.float64).sum(0), t=ta, id0=a0, id1=a1, u=ua, v=va,
                         n_inner=np.uint64(c["n_inner"]), n_tri=np.uint64(c["n_tri"]))
     textured()
+    glossy_area()
     print("golden vectors written to", HERE)
 
 
