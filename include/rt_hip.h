@@ -31,7 +31,16 @@ enum rt_status {
 };
 
 /* Light kinds of src/lights/LightSource.hpp:12-17 that the reference implements. */
-enum rt_light_type { RT_LIGHT_POINT = 0, RT_LIGHT_ENV = 3 };
+enum rt_light_type { RT_LIGHT_POINT = 0, RT_LIGHT_AREA = 2, RT_LIGHT_ENV = 3 };
+
+/* Glossy lobe of a material.  NONE is the reference as shipped: its
+ * Torrance-Sparrow lobe only exists inside a comment
+ * (src/scene/Material.cpp:205-209).  BECKMANN adds that lobe
+ * (src/bsdf/Microfacet.cpp, with the reflected direction and the inverse error
+ * function corrected), GGX the same lobe over a Trowbridge-Reitz distribution;
+ * parameters as in the comment: alpha = (roughness, roughness + 0.1),
+ * FresnelConductor(0.5, 0.5, diffuse colour), R = 1. */
+enum rt_glossy { RT_GLOSSY_NONE = 0, RT_GLOSSY_BECKMANN = 1, RT_GLOSSY_GGX = 2 };
 
 /* Per-model material: the part of MaterialUBO (src/scene/Material.hpp:17-21)
  * that Material::computeBSDF reads (src/scene/Material.cpp:195-225). */
@@ -40,6 +49,7 @@ typedef struct rt_material {
     float roughness;
     int32_t texture;         /* index into rt_scene_desc.textures (Material::_diffTexture,
                                 src/scene/Material.hpp:61), or -1 for none */
+    int32_t glossy;          /* rt_glossy */
 } rt_material;
 
 /* Diffuse map: the RGBA8 image Material::setDiffuseTexture loads
@@ -51,13 +61,18 @@ typedef struct rt_texture {
 } rt_texture;
 
 /* PointLight{pos = light2world*(0,0,0,1), I} (src/lights/PointLight.cpp:9-18)
- * or EnvLight{RGBA32F lat-long image, scale} (src/lights/EnvLight.cpp:14-26). */
+ * or EnvLight{RGBA32F lat-long image, scale} (src/lights/EnvLight.cpp:14-26),
+ * or an area light: one emissive triangle behind the LightSource interface
+ * (src/lights/LightSource.hpp:15 names the type, the reference has no class
+ * for it): uniform area sampling, one-sided radiance `intensity` on the side
+ * of cross(p1-p0, p2-p0), shadow rays bounded at the sampled point. */
 typedef struct rt_light {
     int32_t type;            /* rt_light_type */
     float pos[3];            /* point only */
     float intensity[3];      /* point: I; env: the `light` scale */
     const float* env_rgba;   /* env only: env_w*env_h*4 floats, row-major */
     int32_t env_w, env_h;
+    float p0[3], p1[3], p2[3]; /* area only */
 } rt_light;
 
 /* The scene as BVH::runLBVH sees it (src/scene/BVH.cpp:293-317): all models'

@@ -25,7 +25,8 @@ class RtError(RuntimeError):
 
 
 class rt_material(C.Structure):
-    _fields_ = [("diffuse_color", C.c_float * 3), ("roughness", C.c_float), ("texture", C.c_int32)]
+    _fields_ = [("diffuse_color", C.c_float * 3), ("roughness", C.c_float), ("texture", C.c_int32),
+                ("glossy", C.c_int32)]
 
 
 class rt_texture(C.Structure):
@@ -34,7 +35,8 @@ class rt_texture(C.Structure):
 
 class rt_light(C.Structure):
     _fields_ = [("type", C.c_int32), ("pos", C.c_float * 3), ("intensity", C.c_float * 3),
-                ("env_rgba", C.POINTER(C.c_float)), ("env_w", C.c_int32), ("env_h", C.c_int32)]
+                ("env_rgba", C.POINTER(C.c_float)), ("env_w", C.c_int32), ("env_h", C.c_int32),
+                ("p0", C.c_float * 3), ("p1", C.c_float * 3), ("p2", C.c_float * 3)]
 
 
 class rt_scene_desc(C.Structure):
@@ -154,6 +156,7 @@ class Context:
             mats[m].diffuse_color[:] = [float(x) for x in s.materials[m, :3]]
             mats[m].roughness = float(s.materials[m, 3])
             mats[m].texture = int(s.material_texture[m])
+            mats[m].glossy = int(s.material_glossy[m])
         textures = (rt_texture * max(1, len(s.textures)))()
         for i, t in enumerate(s.textures):
             t = np.ascontiguousarray(t, np.uint8)
@@ -165,6 +168,9 @@ class Context:
             lights[i].type = l.type
             lights[i].pos[:] = [float(x) for x in l.pos]
             lights[i].intensity[:] = [float(x) for x in l.intensity]
+            if l.tri is not None:
+                for name, pt in zip(("p0", "p1", "p2"), l.tri):
+                    getattr(lights[i], name)[:] = [float(x) for x in pt]
             if l.type == LIGHT_ENV:
                 env = np.ascontiguousarray(l.env, np.float32)
                 self._keep.append(env)

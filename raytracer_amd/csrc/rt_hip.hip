@@ -58,6 +58,8 @@ struct rt_ctx {
     float4* d_materials = nullptr;
     DevLight* d_lights = nullptr;
     int32_t* d_material_texture = nullptr;
+    int32_t* d_material_glossy = nullptr;
+    bool any_glossy = false, any_area = false;
     DevTexture* d_textures = nullptr;
     TexLevel* d_tex_levels = nullptr;
     uchar4* d_texels = nullptr;
@@ -299,16 +301,27 @@ int run_pass(rt_ctx* c) {
         uint32_t* sqc = c->d_counts + (D + 1) + d;
         // shade(d) overwrites the parity-p buffers that shadow/accumulate(d-2) read
         if (L > 0 && d >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_acc[d - 2], 0));
-        hipLaunchKernelGGL(k_shade, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in, qout,
-                           cnt_out, c->sq[p], sqc);
+        if (c->any_glossy)
+            hipLaunchKernelGGL(k_shade<true>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
+                               qout, cnt_out, c->sq[p], sqc);
+        else
+            hipLaunchKernelGGL(k_shade<false>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
+                               qout, cnt_out, c->sq[p], sqc);
         if (L > 0) {
             HIP_TRY(c, hipEventRecord(c->ev_shade[d], c->stream));
             HIP_TRY(c, hipStreamWaitEvent(c->stream_b, c->ev_shade[d], 0));
             TraceWork* w = work + D + d;
-            hipLaunchKernelGGL(k_shadow<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], sqc, w,
-                               c->d_pass_deferred_b, c->d_raystats + 1);
-            hipLaunchKernelGGL(k_shadow<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], sqc, w,
-                               c->d_pass_deferred_b, c->d_raystats + 1);
+            if (c->any_area) {   // shadow rays towards area lights stop at the light
+                hipLaunchKernelGGL((k_shadow<false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], sqc, w,
+                                   c->d_pass_deferred_b, c->d_raystats + 1);
+                hipLaunchKernelGGL((k_shadow<true, true>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], sqc,
+                                   w, c->d_pass_deferred_b, c->d_raystats + 1);
+            } else {
+                hipLaunchKernelGGL((k_shadow<false, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], sqc, w,
+                                   c->d_pass_deferred_b, c->d_raystats + 1);
+                hipLaunchKernelGGL((k_shadow<true, false>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], sqc,
+                                   w, c->d_pass_deferred_b, c->d_raystats + 1);
+            }
             hipLaunchKernelGGL(k_accumulate, dim3(gshade), dim3(RT_BLOCK), 0, c->stream_b, pbd, c->sq[p], L, qin, cnt_in);
             HIP_TRY(c, hipEventRecord(c->ev_acc[d], c->stream_b));
         }
@@ -386,6 +399,11 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         if (!sd->textures[t].rgba8 || sd->textures[t].width < 1 || sd->textures[t].height < 1 || sd->textures[t].width > 32768 ||
             sd->textures[t].height > 32768) {
             c->err = "texture needs texels and a size of 1..32768 in each direction";
+            return RT_ERR_ARG;
+        }
+    for (uint32_t m = 0; m < sd->n_models; ++m)
+        if (sd->materials[m].glossy < RT_GLOSSY_NONE || sd->materials[m].glossy > RT_GLOSSY_GGX) {
+            c->err = "material glossy must be 0 (none), 1 (Beckmann) or 2 (GGX)";
             return RT_ERR_ARG;
         }
     for (uint32_t m = 0; m < sd->n_models; ++m)
@@ -531,6 +549,12 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
             mats[m] = make_float4(sd->materials[m].diffuse_color[0], sd->materials[m].diffuse_color[1],
                                   sd->materials[m].diffuse_color[2], sd->materials[m].roughness);
         if ((r = dev_upload(c, &c->d_materials, mats.data(), mats.size()))) return r;
+        std::vector<int32_t> mg(sd->n_models);
+        for (uint32_t m = 0; m < sd->n_models; ++m) {
+            mg[m] = sd->materials[m].glossy;
+            if (mg[m] != RT_GLOSSY_NONE) c->any_glossy = true;
+        }
+        if (c->any_glossy && (r = dev_upload(c, &c->d_material_glossy, mg.data(), mg.size()))) return r;
     }
     // ---- diffuse maps: mip chains by 2x2 box average in integers, (a+b+c+d+2)>>2,
     // level sizes max(1, w>>1); all levels of all maps in one texel buffer
@@ -592,8 +616,25 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
             d.ix = s.intensity[0]; d.iy = s.intensity[1]; d.iz = s.intensity[2];
             if (s.type == RT_LIGHT_ENV) {
                 if ((r = build_env(c, s, d, c->env[l]))) return r;
+            } else if (s.type == RT_LIGHT_AREA) {
+                float e1[3], e2[3];
+                for (int k = 0; k < 3; ++k) {
+                    d.p0[k] = s.p0[k]; d.p1[k] = s.p1[k]; d.p2[k] = s.p2[k];
+                    e1[k] = s.p1[k] - s.p0[k]; e2[k] = s.p2[k] - s.p0[k];
+                }
+                // glm::cross / glm::normalize operand order, rounded as the scalar reference does
+                float cx = e1[1] * e2[2] - e2[1] * e1[2], cy = e1[2] * e2[0] - e2[2] * e1[0], cz = e1[0] * e2[1] - e2[0] * e1[1];
+                float l2 = cx * cx + cy * cy + cz * cz;
+                if (!(l2 > 0.f) || !std::isfinite(l2)) {
+                    c->err = "area light triangle is degenerate";
+                    return RT_ERR_ARG;
+                }
+                d.area = 0.5f * std::sqrt(l2);
+                float il = 1.0f / std::sqrt(l2);
+                d.n[0] = cx * il; d.n[1] = cy * il; d.n[2] = cz * il;
+                c->any_area = true;
             } else if (s.type != RT_LIGHT_POINT) {
-                c->err = "unsupported light type (point = 0 and env = 3 are implemented)";
+                c->err = "unsupported light type (point = 0, area = 2 and env = 3 are implemented)";
                 return RT_ERR_ARG;
             }
         }
@@ -604,6 +645,7 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     c->ss.lights = c->d_lights;
     c->ss.n_lights = c->n_lights;
     c->ss.material_texture = c->d_material_texture;
+    c->ss.material_glossy = c->d_material_glossy;
     c->ss.textures = c->d_textures;   // null without diffuse maps
     c->ss.tex_levels = c->d_tex_levels;
     c->ss.texels = c->d_texels;
@@ -684,6 +726,8 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
             if ((r = dev_alloc(c, &q.slot, cap))) return r;
             if ((r = dev_alloc(c, &q.light, cap))) return r;
             if ((r = dev_alloc(c, &q.dir, 3 * cap))) return r;
+            q.tmax = nullptr;
+            if (c->any_area && (r = dev_alloc(c, &q.tmax, cap))) return r;
             if ((r = dev_alloc(c, &q.contrib, 6 * cap))) return r;
             if ((r = dev_alloc(c, &q.state, cap))) return r;
         }

@@ -10,7 +10,12 @@
 namespace rt {
 
 #define RT_LIGHT_POINT_K 0
+#define RT_LIGHT_AREA_K 2
 #define RT_LIGHT_ENV_K 3
+
+#define RT_GLOSSY_NONE_K 0
+#define RT_GLOSSY_BECKMANN_K 1
+#define RT_GLOSSY_GGX_K 2
 
 struct DevLight {
     int32_t type;
@@ -25,6 +30,9 @@ struct DevLight {
     const float* cond_int;   // [W] (also the marginal's func)
     const float* marg_cdf;   // [W+1]
     float marg_int;
+    // area: one emissive triangle, radiance (ix, iy, iz) on the side of n = cross(p1-p0, p2-p0)
+    float p0[3], p1[3], p2[3], n[3];
+    float area;
 };
 
 struct PathBuffers {
@@ -58,6 +66,7 @@ struct ShadeScene {
     const float* tri_attr;      // 36 floats per triangle: 3 x (normal3 uv2 tangent3 binormal3), 3 pad
     const float4* materials;    // per model: rgb, roughness
     const int32_t* material_texture;  // per model: texture index or -1
+    const int32_t* material_glossy;   // per model: 0 none, 1 Beckmann, 2 GGX lobe; null when no model has one
     const DevTexture* textures;       // null when the scene has no diffuse maps
     const TexLevel* tex_levels;
     const uchar4* texels;
@@ -173,38 +182,288 @@ RT_DEV f3 diffuse_sampled(const DiffuseK& k, f3 out, f2 u, f3& in, float& pdf) {
     return diffuse_f(k, out, in);
 }
 
-// BSDF with its single Diffuse lobe, src/bsdf/BSDF.cpp:7-104
+// --------------------------------------------------------- glossy lobe
+// Torrance-Sparrow reflection lobe of src/bsdf/Microfacet.cpp (which
+// Material::computeBSDF only mentions in a comment, src/scene/Material.cpp:205-209)
+// as an option of a material.  Two corrections, without which the lobe cannot
+// be sampled: the reflected direction is -out + 2 (out.wh) wh (Microfacet.cpp:216
+// mirrors an incident vector instead), and the Beckmann slope sampler uses the
+// inverse error function where Microfacet.cpp:57,76 calls erfc.  GGX is the
+// published Trowbridge-Reitz distribution (pbrt-v3, src/core/microfacet.cpp).
+RT_DEV float cos2_theta(f3 w) { return w.z * w.z; }
+RT_DEV float tan_theta(f3 w) { return sin_theta(w) / w.z; }
+RT_DEV float tan2_theta(f3 w) { return sin2_theta(w) / cos2_theta(w); }
+RT_DEV float cos2_phi(f3 w) { return cos_phi(w) * cos_phi(w); }
+RT_DEV float sin2_phi(f3 w) { return sin_phi(w) * sin_phi(w); }
+
+// pbrt-v3 src/core/pbrt.h ErfInv
+RT_DEV float erf_inv(float x) {
+    float w, p;
+    x = clampf(x, -.99999f, .99999f);
+    w = -logf((1 - x) * (1 + x));
+    if (w < 5) {
+        w = w - 2.5f;
+        p = 2.81022636e-08f;
+        p = 3.43273939e-07f + p * w;
+        p = -3.5233877e-06f + p * w;
+        p = -4.39150654e-06f + p * w;
+        p = 0.00021858087f + p * w;
+        p = -0.00125372503f + p * w;
+        p = -0.00417768164f + p * w;
+        p = 0.246640727f + p * w;
+        p = 1.50140941f + p * w;
+    } else {
+        w = sqrtf(w) - 3;
+        p = -0.000200214257f;
+        p = 0.000100950558f + p * w;
+        p = 0.00134934322f + p * w;
+        p = -0.00367342844f + p * w;
+        p = 0.00573950773f + p * w;
+        p = -0.0076224613f + p * w;
+        p = 0.00943887047f + p * w;
+        p = 1.00167406f + p * w;
+        p = 2.83297682f + p * w;
+    }
+    return p * x;
+}
+// pbrt-v3 src/core/pbrt.h Erf, in place of the libm erf of Microfacet.cpp:30
+RT_DEV float erf_poly(float x) {
+    const float a1 = 0.254829592f, a2 = -0.284496736f, a3 = 1.421413741f, a4 = -1.453152027f, a5 = 1.061405429f;
+    const float p = 0.3275911f;
+    int sign = 1;
+    if (x < 0) sign = -1;
+    x = fabsf(x);
+    float t = 1 / (1 + p * x);
+    float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * expf(-x * x);
+    return sign * y;
+}
+
+// src/bsdf/Microfacet.cpp:7-80
+RT_DEV void beckmann_sample11(float cosThetaI, float U1, float U2, float& slope_x, float& slope_y) {
+    if ((double)cosThetaI > .9999) {
+        float r = sqrtf(-logf(1.0f - U1));
+        float sinPhi = sinf(2 * kPi * U2);
+        float cosPhi = cosf(2 * kPi * U2);
+        slope_x = r * cosPhi;
+        slope_y = r * sinPhi;
+        return;
+    }
+    float sinThetaI = sqrtf(gmax(0.f, 1.f - cosThetaI * cosThetaI));
+    float tanThetaI = sinThetaI / cosThetaI;
+    float cotThetaI = 1 / tanThetaI;
+    float a = -1, c = erf_poly(cotThetaI);
+    float sample_x = gmax(U1, 1e-6f);
+    float thetaI = acosf(cosThetaI);
+    float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
+    float b = c - (1 + c) * powf(1 - sample_x, fit);
+    const float SQRT_PI_INV = 1.f / sqrtf(kPi);
+    float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+    int it = 0;
+    while (++it < 10) {
+        if (!(b >= a && b <= c)) b = 0.5f * (a + c);
+        float invErf = erf_inv(b);
+        float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * expf(-invErf * invErf)) - sample_x;
+        float derivative = normalization * (1 - invErf * tanThetaI);
+        if (fabsf(value) < 1e-5f) break;
+        if (value > 0)
+            c = b;
+        else
+            a = b;
+        b -= value / derivative;
+    }
+    slope_x = erf_inv(b);
+    slope_y = erf_inv(2.0f * gmax(U2, 1e-6f) - 1.0f);
+}
+// pbrt-v3 TrowbridgeReitzSample11
+RT_DEV void ggx_sample11(float cosTheta, float U1, float U2, float& slope_x, float& slope_y) {
+    if ((double)cosTheta > .9999) {
+        float r = sqrtf(U1 / (1 - U1));
+        float phi = 6.28318530718f * U2;
+        slope_x = r * cosf(phi);
+        slope_y = r * sinf(phi);
+        return;
+    }
+    float sinTheta = sqrtf(gmax(0.f, 1.f - cosTheta * cosTheta));
+    float tanTheta = sinTheta / cosTheta;
+    float a = 1 / tanTheta;
+    float G1 = 2 / (1 + sqrtf(1.f + 1.f / (a * a)));
+    float A = 2 * U1 / G1 - 1;
+    float tmp = 1.f / (A * A - 1.f);
+    if (tmp > 1e10f) tmp = 1e10f;
+    float B = tanTheta;
+    float D = sqrtf(gmax(B * B * tmp * tmp - (A * A - B * B) * tmp, 0.f));
+    float slope_x_1 = B * tmp - D;
+    float slope_x_2 = B * tmp + D;
+    slope_x = (A < 0 || slope_x_2 > 1.f / tanTheta) ? slope_x_1 : slope_x_2;
+    float S;
+    if (U2 > 0.5f) {
+        S = 1.f;
+        U2 = 2.f * (U2 - .5f);
+    } else {
+        S = -1.f;
+        U2 = 2.f * (.5f - U2);
+    }
+    float z = (U2 * (U2 * (U2 * 0.27385f - 0.73369f) + 0.46341f)) / (U2 * (U2 * (U2 * 0.093073f + 0.309420f) - 1.000000f) + 0.597999f);
+    slope_y = S * z * sqrtf(1.f + slope_x * slope_x);
+}
+
+// MicrofacetDistribution with visible-area sampling, src/bsdf/Microfacet.hpp:9-50
+struct MicrofacetK {
+    int kind;
+    float ax, ay;
+};
+RT_DEV float mf_D(const MicrofacetK& m, f3 wh) {
+    float t2 = tan2_theta(wh);
+    if (isinf(t2)) return 0.f;
+    float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
+    if (m.kind == RT_GLOSSY_BECKMANN_K)
+        return expf(-t2 * (cos2_phi(wh) / (m.ax * m.ax) + sin2_phi(wh) / (m.ay * m.ay))) / (kPi * m.ax * m.ay * cos4Theta);
+    float e = (cos2_phi(wh) / (m.ax * m.ax) + sin2_phi(wh) / (m.ay * m.ay)) * t2;
+    return 1 / (kPi * m.ax * m.ay * cos4Theta * (1 + e) * (1 + e));
+}
+RT_DEV float mf_lambda(const MicrofacetK& m, f3 w) {
+    float absTanTheta = fabsf(tan_theta(w));
+    if (isinf(absTanTheta)) return 0.f;
+    float alpha = sqrtf(cos2_phi(w) * m.ax * m.ax + sin2_phi(w) * m.ay * m.ay);
+    if (m.kind == RT_GLOSSY_BECKMANN_K) {
+        float a = 1 / (alpha * absTanTheta);
+        if (a >= 1.6f) return 0;
+        return (1 - 1.259f * a + 0.396f * a * a) / (3.535f * a + 2.181f * a * a);
+    }
+    float alpha2Tan2Theta = (alpha * absTanTheta) * (alpha * absTanTheta);
+    return (-1 + sqrtf(1.f + alpha2Tan2Theta)) / 2;
+}
+RT_DEV float mf_G1(const MicrofacetK& m, f3 w) { return 1 / (1 + mf_lambda(m, w)); }
+RT_DEV float mf_G(const MicrofacetK& m, f3 wo, f3 wi) { return 1 / (1 + mf_lambda(m, wo) + mf_lambda(m, wi)); }
+RT_DEV f3 mf_sample_wh(const MicrofacetK& m, f3 wo, f2 u) {
+    bool flip = wo.z < 0;
+    f3 wi = flip ? -wo : wo;
+    f3 ws = normalize3(mk3(m.ax * wi.x, m.ay * wi.y, wi.z));
+    float slope_x, slope_y;
+    if (m.kind == RT_GLOSSY_BECKMANN_K)
+        beckmann_sample11(ws.z, u.x, u.y, slope_x, slope_y);
+    else
+        ggx_sample11(ws.z, u.x, u.y, slope_x, slope_y);
+    float tmp = cos_phi(ws) * slope_x - sin_phi(ws) * slope_y;
+    slope_y = sin_phi(ws) * slope_x + cos_phi(ws) * slope_y;
+    slope_x = tmp;
+    slope_x = m.ax * slope_x;
+    slope_y = m.ay * slope_y;
+    f3 wh = normalize3(mk3(-slope_x, -slope_y, 1.f));
+    if (flip) wh = -wh;
+    return wh;
+}
+RT_DEV float mf_pdf(const MicrofacetK& m, f3 wo, f3 wh) { return mf_D(m, wh) * mf_G1(m, wo) * fabsf(dot3(wo, wh)) / abs_cos_theta(wo); }
+
+RT_DEV f3 sqrt3(f3 v) { return mk3(sqrtf(v.x), sqrtf(v.y), sqrtf(v.z)); }
+RT_DEV f3 splat3(float a) { return mk3(a, a, a); }
+// src/bsdf/Microfacet.cpp:176-198
+RT_DEV f3 fresnel_conductor(f3 etaI, f3 etaT, f3 k, float cosI) {
+    float cosThetaI = clampf(cosI, -1, 1);
+    f3 eta = etaT / etaI;
+    f3 etak = k / etaI;
+    float cosThetaI2 = cosThetaI * cosThetaI;
+    float sinThetaI2 = 1.f - cosThetaI2;
+    f3 eta2 = eta * eta;
+    f3 etak2 = etak * etak;
+    f3 t0 = eta2 - etak2 - splat3(sinThetaI2);
+    f3 a2plusb2 = sqrt3(t0 * t0 + 4.f * eta2 * etak2);
+    f3 t1 = a2plusb2 + splat3(cosThetaI2);
+    f3 a = sqrt3(0.5f * (a2plusb2 + t0));
+    f3 t2 = 2.f * cosThetaI * a;
+    f3 Rs = (t1 - t2) / (t1 + t2);
+    f3 t3 = cosThetaI2 * a2plusb2 + splat3(sinThetaI2 * sinThetaI2);
+    f3 t4 = t2 * sinThetaI2;
+    f3 Rp = Rs * (t3 - t4) / (t3 + t4);
+    return 0.5f * (Rp + Rs);
+}
+
+// src/bsdf/Microfacet.cpp:200-228 with the parameters of Material.cpp:205-208:
+// R = 1, FresnelConductor(0.5, 0.5, diffColor)
+struct ReflectionK {
+    MicrofacetK d;
+    f3 k;
+};
+RT_DEV f3 reflection_f(const ReflectionK& r, f3 wo, f3 wi) {
+    float cosThetaO = abs_cos_theta(wo), cosThetaI = abs_cos_theta(wi);
+    f3 wh = wi + wo;
+    if (cosThetaI == 0 || cosThetaO == 0) return mk3(0.f, 0.f, 0.f);
+    if (wh.x == 0 && wh.y == 0 && wh.z == 0) return mk3(0.f, 0.f, 0.f);
+    wh = normalize3(wh);
+    f3 F = fresnel_conductor(splat3(0.5f), splat3(0.5f), r.k, dot3(wi, wh));
+    return mk3(1.f, 1.f, 1.f) * mf_D(r.d, wh) * mf_G(r.d, wo, wi) * F / (4 * cosThetaI * cosThetaO);
+}
+RT_DEV f3 reflection_sampled(const ReflectionK& r, f3 out, f2 u, f3& in, float& pdf) {
+    if (out.z == 0) return mk3(0.f, 0.f, 0.f);
+    f3 wh = mf_sample_wh(r.d, out, u);
+    in = -out + 2.f * dot3(out, wh) * wh;
+    if (!(out.z * in.z > 0)) return mk3(0.f, 0.f, 0.f);
+    pdf = mf_pdf(r.d, out, wh) / (4.f * dot3(out, wh));
+    return reflection_f(r, out, in);
+}
+RT_DEV float reflection_pdf(const ReflectionK& r, f3 wo, f3 wi) {
+    if (!(wo.z * wi.z > 0)) return 0;
+    f3 wh = normalize3(wo + wi);
+    return mf_pdf(r.d, wo, wh) / (4.f * dot3(wo, wh));
+}
+
+// BSDF, src/bsdf/BSDF.cpp:7-104: the Diffuse lobe, plus the Reflection lobe
+// when the material carries one (GLOSSY kernels only)
 struct BsdfK {
     f3 t, b, n;
     DiffuseK lobe;
+    ReflectionK glossy;
+    int parts;
 };
 RT_DEV f3 world2local(const BsdfK& s, f3 v) { return mk3(dot3(s.t, v), dot3(s.b, v), dot3(s.n, v)); }
 RT_DEV f3 local2world(const BsdfK& s, f3 v) {
     return mk3(s.t.x * v.x + s.b.x * v.y + s.n.x * v.z, s.t.y * v.x + s.b.y * v.y + s.n.y * v.z,
                s.t.z * v.x + s.b.z * v.y + s.n.z * v.z);
 }
+template <bool GLOSSY>
 RT_DEV f3 bsdf_f(const BsdfK& s, f3 outW, f3 inW) {
     f3 in = world2local(s, inW), out = world2local(s, outW);
     bool reflect = dot3(inW, s.n) * dot3(outW, s.n) > 0;
     f3 r = mk3(0.f, 0.f, 0.f);
     if (reflect) r = r + diffuse_f(s.lobe, out, in);
+    if (GLOSSY && reflect && s.parts > 1) r = r + reflection_f(s.glossy, out, in);
     return r;
 }
+template <bool GLOSSY>
 RT_DEV float bsdf_pdf(const BsdfK& s, f3 outW, f3 inW) {
     f3 out = world2local(s, outW), in = world2local(s, inW);
     float p = 0.f;
     p += diffuse_pdf(out, in);
-    p /= 1.0f;
+    if (GLOSSY && s.parts > 1) {
+        p += reflection_pdf(s.glossy, out, in);
+        p /= 2.0f;
+    } else {
+        p /= 1.0f;
+    }
     return p;
 }
+template <bool GLOSSY>
 RT_DEV f3 bsdf_sample(const BsdfK& s, f3 outW, f2 u, f3& inW, float& pdf) {
     pdf = 0.f;
-    int comp = min((int)floorf(u.x * 1), 0);
-    f2 uR; uR.x = u.x * 1 - comp; uR.y = u.y;
-    f3 wi, wo = world2local(s, outW);
-    f3 fr = diffuse_sampled(s.lobe, wo, uR, wi, pdf);
+    const int mc = (GLOSSY && s.parts > 1) ? 2 : 1;
+    int comp = min((int)floorf(u.x * mc), mc - 1);
+    f2 uR; uR.x = u.x * mc - comp; uR.y = u.y;
+    f3 wi = mk3(0.f, 0.f, 0.f), wo = world2local(s, outW);
+    f3 fr;
+    if (GLOSSY && comp == 1) fr = reflection_sampled(s.glossy, wo, uR, wi, pdf);
+    else fr = diffuse_sampled(s.lobe, wo, uR, wi, pdf);
     if (pdf == 0) return mk3(0.f, 0.f, 0.f);
     inW = local2world(s, wi);
+    if (GLOSSY && mc > 1) {
+        pdf += comp == 0 ? reflection_pdf(s.glossy, wo, wi) : diffuse_pdf(wo, wi);
+        pdf /= mc;
+        bool reflect = dot3(inW, s.n) * dot3(outW, s.n) > 0;
+        fr = mk3(0.f, 0.f, 0.f);
+        if (reflect) {
+            fr = fr + diffuse_f(s.lobe, wo, wi);
+            fr = fr + reflection_f(s.glossy, wo, wi);
+        }
+    }
     return fr;
 }
 
@@ -307,13 +566,36 @@ RT_DEV f2 hit_uv(const float* tri_attr, int32_t id1, float hu, float hv) {
 
 // ----------------------------------------------------------------- lights
 // src/lights/PointLight.cpp:14-18, src/lights/EnvLight.cpp:28-43
-RT_DEV f3 light_sample(const DevLight& l, f3 p, f2 u, f3& in, float& pdf) {
+// tmax: where the shadow ray towards the sample stops (+inf for the
+// reference's lights, whose shadow rays are unbounded).  Area lights (one
+// emissive triangle; the reference only names the type, LightSource.hpp:15)
+// follow the published DiffuseAreaLight-over-Triangle model: uniform area
+// sampling, pdf dist^2 / (|cos| area), one-sided emission.
+RT_DEV f3 light_sample(const DevLight& l, f3 p, f2 u, f3& in, float& pdf, float& tmax) {
+    tmax = __builtin_inff();
     if (l.type == RT_LIGHT_POINT_K) {
         f3 lp = mk3(l.px, l.py, l.pz);
         in = normalize3(lp - p);
         pdf = 1.f;
         f3 d = lp - p;
         return mk3(l.ix, l.iy, l.iz) / dot3(d, d);
+    }
+    if (l.type == RT_LIGHT_AREA_K) {
+        float su0 = sqrtf(u.x);
+        float b0 = 1.f - su0, b1 = u.y * su0;
+        f3 q = mk3(l.p0[0], l.p0[1], l.p0[2]) * b0 + mk3(l.p1[0], l.p1[1], l.p1[2]) * b1 + mk3(l.p2[0], l.p2[1], l.p2[2]) * (1.f - b0 - b1);
+        f3 w = q - p;
+        float d2 = dot3(w, w);
+        pdf = 0.0f;
+        in = mk3(0.f, 0.f, 0.f);
+        if (d2 == 0) return mk3(0.f, 0.f, 0.f);
+        float d = sqrtf(d2);
+        in = w / d;
+        float cosL = dot3(mk3(l.n[0], l.n[1], l.n[2]), -in);
+        pdf = d2 / (fabsf(cosL) * l.area);
+        if (!isfinite(pdf)) { pdf = 0.0f; return mk3(0.f, 0.f, 0.f); }
+        tmax = d * (1.0f - 1e-4f);
+        return cosL > 0 ? mk3(l.ix, l.iy, l.iz) : mk3(0.f, 0.f, 0.f);
     }
     // Distribution2D::sampleContinuous, src/samplers/Distributions.cpp:60-68
     float pdf0, pdf1;
@@ -335,8 +617,15 @@ RT_DEV f3 light_sample(const DevLight& l, f3 p, f2 u, f3& in, float& pdf) {
 }
 // src/lights/PointLight.cpp:20-22, src/lights/EnvLight.cpp:45-52 with
 // Distribution2D::pdf, src/samplers/Distributions.cpp:70-76
-RT_DEV float light_pdf(const DevLight& l, f3 inW) {
+RT_DEV float light_pdf(const DevLight& l, f3 p, f3 inW) {
     if (l.type == RT_LIGHT_POINT_K) return 1.0f;
+    if (l.type == RT_LIGHT_AREA_K) {
+        float t, bu, bv;
+        if (!tri_test(p, inW, mk3(l.p0[0], l.p0[1], l.p0[2]), mk3(l.p1[0], l.p1[1], l.p1[2]), mk3(l.p2[0], l.p2[1], l.p2[2]), t, bu, bv)) return 0;
+        if (!(t > 0.0001f)) return 0;
+        float pd = (t * t) / (fabsf(dot3(mk3(l.n[0], l.n[1], l.n[2]), -inW)) * l.area);
+        return isfinite(pd) ? pd : 0;
+    }
     float theta = spherical_theta(inW), phi = spherical_phi(inW);
     float sinT = sinf(theta);
     if (sinT == 0) return 0.f;
@@ -348,7 +637,7 @@ RT_DEV float light_pdf(const DevLight& l, f3 inW) {
 }
 // src/lights/LightSource.hpp:28-30, src/lights/EnvLight.cpp:60-65
 RT_DEV f3 light_le(const DevLight& l, f3 dir) {
-    if (l.type == RT_LIGHT_POINT_K) return mk3(0.f, 0.f, 0.f);
+    if (l.type != RT_LIGHT_ENV_K) return mk3(0.f, 0.f, 0.f);
     f3 w = normalize3(dir);
     f2 st; st.x = spherical_phi(w) * kInv2Pi; st.y = spherical_theta(w) * kInvPi;
     return filter_linear(l.img, l.W, l.H, st);
@@ -466,6 +755,7 @@ struct ShadowQueue {
     uint32_t* slot;    // [cap]
     uint32_t* light;   // [cap]
     float* dir;        // 3 planes of cap
+    float* tmax;       // [cap] far bound of each ray, or null when the scene has no area light
     float* contrib;    // 6 planes of cap, indexed light * n_slots + slot
     uint8_t* state;    // [cap], indexed light * n_slots + slot
     uint32_t cap;      // n_lights * n_slots
@@ -476,6 +766,7 @@ struct ShadowQueue {
 // Material::computeBSDF (src/scene/Material.cpp:214-225), per-light sampling
 // with the contributions the reference would add once the shadow ray is
 // found unoccluded, then the BSDF bounce.
+template <bool GLOSSY>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene sc, int depth, int max_depth, uint64_t seed_mixed,
                                                     uint32_t pass, const uint32_t* __restrict__ queue,
                                                     const uint32_t* __restrict__ d_count, uint32_t* __restrict__ next_queue,
@@ -511,6 +802,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
         BsdfK bsdf;
         bsdf.t = mk3(1.f, 0.f, 0.f); bsdf.b = mk3(0.f, 1.f, 0.f); bsdf.n = mk3(0.f, 0.f, 1.f);
         bsdf.lobe = make_diffuse(mk3(0.f, 0.f, 0.f), 0.f);
+        bsdf.parts = 1;
+        bsdf.glossy.d.kind = RT_GLOSSY_NONE_K; bsdf.glossy.d.ax = 1.f; bsdf.glossy.d.ay = 1.f;
+        bsdf.glossy.k = mk3(0.f, 0.f, 0.f);
         f3 vpos = mk3(0.f, 0.f, 0.f), vn = mk3(0.f, 0.f, 1.f), out = mk3(0.f, 0.f, 1.f);
         f3 beta = mk3(1.f, 1.f, 1.f);
         uint32_t pixel = 0;
@@ -565,6 +859,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
             col = col * mk3(m.x, m.y, m.z);
             bsdf.t = tan; bsdf.b = bin; bsdf.n = nrm;
             bsdf.lobe = make_diffuse(col, m.w);
+            if (GLOSSY) {
+                // the lobe of src/scene/Material.cpp:205-208: alpha = (roughness, roughness + 0.1), k = diffColor
+                int g = sc.material_glossy[id0];
+                if (g != RT_GLOSSY_NONE_K) {
+                    bsdf.parts = 2;
+                    bsdf.glossy.d.kind = g;
+                    bsdf.glossy.d.ax = m.w;
+                    bsdf.glossy.d.ay = m.w + 0.1f;
+                    bsdf.glossy.k = col;
+                }
+            }
             out = -dir;
             pb.vpos[s] = vpos.x; pb.vpos[n + s] = vpos.y; pb.vpos[2 * n + s] = vpos.z;
             beta = mk3(pb.beta[s], pb.beta[n + s], pb.beta[2 * n + s]);
@@ -574,17 +879,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
         for (int l = 0; l < L; ++l) {
             bool emit = false;
             f3 in = mk3(0.f, 0.f, 0.f), C = mk3(0.f, 0.f, 0.f), C2 = mk3(0.f, 0.f, 0.f);
+            float tmax = __builtin_inff();
             if (hit) {
                 const DevLight& light = sc.lights[l];
                 float lightPdf;
                 f2 u;
                 u.x = rng_u01(seed_mixed, pixel, pass, dim_light(depth, L, l, 0));
                 u.y = rng_u01(seed_mixed, pixel, pass, dim_light(depth, L, l, 1));
-                f3 li = light_sample(light, vpos, u, in, lightPdf);
+                f3 li = light_sample(light, vpos, u, in, lightPdf, tmax);
                 if (lightPdf != 0.0f) {
                     emit = true;
-                    f3 bsdfColor = bsdf_f(bsdf, out, in);
-                    float bsdfPdf = bsdf_pdf(bsdf, out, in);
+                    f3 bsdfColor = bsdf_f<GLOSSY>(bsdf, out, in);
+                    float bsdfPdf = bsdf_pdf<GLOSSY>(bsdf, out, in);
                     if (light.type == RT_LIGHT_POINT_K) {
                         C = beta * bsdfColor * li / lightPdf;
                     } else {
@@ -593,10 +899,10 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
                         f2 u2;
                         u2.x = rng_u01(seed_mixed, pixel, pass, dim_light(depth, L, l, 2));
                         u2.y = rng_u01(seed_mixed, pixel, pass, dim_light(depth, L, l, 3));
-                        f3 f = bsdf_sample(bsdf, out, u2, inBSDF, bsdfPdf);
+                        f3 f = bsdf_sample<GLOSSY>(bsdf, out, u2, inBSDF, bsdfPdf);
                         if (bsdfPdf != 0.0f) {
                             f = f * fabsf(dot3(in, vn));
-                            float lp = light_pdf(light, in);
+                            float lp = light_pdf(light, vpos, in);
                             if (lp != 0.0f) {
                                 float weight = power_heuristic(bsdfPdf, lp);
                                 f3 li2 = light_le(light, dir);
@@ -616,6 +922,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
                 sq.slot[k] = s;
                 sq.light[k] = (uint32_t)l;
                 sq.dir[k] = in.x; sq.dir[cap + k] = in.y; sq.dir[2 * cap + k] = in.z;
+                if (sq.tmax) sq.tmax[k] = tmax;
                 sq.contrib[e] = C.x; sq.contrib[cap + e] = C.y; sq.contrib[2 * cap + e] = C.z;
                 sq.contrib[3 * cap + e] = C2.x; sq.contrib[4 * cap + e] = C2.y; sq.contrib[5 * cap + e] = C2.z;
             }
@@ -630,7 +937,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
             f2 u3;
             u3.x = rng_u01(seed_mixed, pixel, pass, dim_bounce(depth, L, 0));
             u3.y = rng_u01(seed_mixed, pixel, pass, dim_bounce(depth, L, 1));
-            f3 bsdfColor = bsdf_sample(bsdf, out, u3, nextDir, nextPDF);
+            f3 bsdfColor = bsdf_sample<GLOSSY>(bsdf, out, u3, nextDir, nextPDF);
             if (!(is_zero3(bsdfColor) || nextPDF == 0.0f)) {
                 alive = true;
                 beta = beta * (bsdfColor * fabsf(dot3(nextDir, vn)) / nextPDF);
@@ -648,7 +955,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
 // BVH::occluded from the shaded vertex (src/cpu/PathTracer.cpp:101-102).  An
 // unoccluded ray only marks its (light, slot) state; k_accumulate then adds
 // the contributions in the reference's order.
-template <bool EXACT>
+template <bool EXACT, bool BOUNDED>
 __global__ __launch_bounds__(RT_TBLOCK) void k_shadow(TraceScene ts, PathBuffers pb, ShadowQueue q, const uint32_t* __restrict__ d_count,
                                                      TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
                                                      unsigned long long* __restrict__ ray_counter) {
@@ -658,16 +965,29 @@ __global__ __launch_bounds__(RT_TBLOCK) void k_shadow(TraceScene ts, PathBuffers
     const uint32_t count = EXACT ? work->n_deferred : *d_count;
     const size_t n = pb.n, cap = q.cap;
     if (!EXACT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)count);
-    trace_persistent<true, EXACT>(
-        ts, count, work, deferred, s_stack, top,
-        [&](uint32_t i, f3& org, f3& dir) {
-            uint32_t s = q.slot[i];
-            org = mk3(pb.vpos[s], pb.vpos[n + s], pb.vpos[2 * n + s]);
-            dir = mk3(q.dir[i], q.dir[cap + i], q.dir[2 * cap + i]);
-        },
-        [&](uint32_t i, const HitRec& h) {
-            if (h.id1 < 0) q.state[(size_t)q.light[i] * n + q.slot[i]] = 2;
-        });
+    auto mark = [&](uint32_t i, const HitRec& h) {
+        if (h.id1 < 0) q.state[(size_t)q.light[i] * n + q.slot[i]] = 2;
+    };
+    if constexpr (BOUNDED) {
+        trace_persistent<true, EXACT, true>(
+            ts, count, work, deferred, s_stack, top,
+            [&](uint32_t i, f3& org, f3& dir, float& tfar) {
+                uint32_t s = q.slot[i];
+                org = mk3(pb.vpos[s], pb.vpos[n + s], pb.vpos[2 * n + s]);
+                dir = mk3(q.dir[i], q.dir[cap + i], q.dir[2 * cap + i]);
+                tfar = q.tmax[i];
+            },
+            mark);
+    } else {
+        trace_persistent<true, EXACT, false>(
+            ts, count, work, deferred, s_stack, top,
+            [&](uint32_t i, f3& org, f3& dir) {
+                uint32_t s = q.slot[i];
+                org = mk3(pb.vpos[s], pb.vpos[n + s], pb.vpos[2 * n + s]);
+                dir = mk3(q.dir[i], q.dir[cap + i], q.dir[2 * cap + i]);
+            },
+            mark);
+    }
 }
 
 // The adds of src/cpu/PathTracer.cpp:107/:109 and :123 for every path of the

@@ -198,7 +198,12 @@ struct TraceWork {
 // selects) is not traced but appended to `deferred`.  EXACT = true is the
 // follow-up launch over that list (count = work->n_deferred) with the
 // select-based box test; it is almost always empty.
-template <bool ANY_HIT, bool EXACT, typename Load, typename Done>
+//
+// BOUNDED (any-hit only): `load` also yields a far bound; the ray is only
+// occluded by hits in front of it, and the bound takes the place of the
+// never-shrinking hit.dist of the reference's loop (src/scene/BVH.cpp:70,106-107).
+// A bound of +inf is the reference's unbounded shadow ray.
+template <bool ANY_HIT, bool EXACT, bool BOUNDED = false, typename Load, typename Done>
 RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* work, uint32_t* deferred, int32_t* lds_stack,
                              const TopTree& top, Load load, Done done) {
     const uint32_t tid = threadIdx.x;
@@ -227,6 +232,8 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
     f3 org = mk3(0.f, 0.f, 0.f), dir = mk3(0.f, 0.f, 1.f), inv = mk3(0.f, 0.f, 1.f);
     HitRec h;
     h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
+    float tfar = inf;
+    static_assert(!BOUNDED || ANY_HIT, "a far bound only makes sense for any-hit rays");
 
     for (;;) {
         const unsigned long long m_idle = __ballot(!have);
@@ -251,7 +258,8 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     uint32_t i = c_next + r;
                     if (EXACT) i = deferred[i];
                     item = i;
-                    load(i, org, dir);
+                    if constexpr (BOUNDED) load(i, org, dir, tfar);
+                    else load(i, org, dir);
                     inv = make_invdir(dir);
                     h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
                     float rd;
@@ -306,8 +314,9 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     ls = slab_test_fast(org, inv, a.x, a.y, a.z, a.w, b.x, b.y, ld);
                     rs = slab_test_fast(org, inv, b.z, b.w, c.x, c.y, c.z, c.w, rdist);
                 }
-                ls = ls && (ld < h.t);
-                rs = rs && (rdist < h.t);
+                const float bound = BOUNDED ? tfar : h.t;
+                ls = ls && (ld < bound);
+                rs = rs && (rdist < bound);
                 if (ls && rs) {
                     const bool swap = rdist < ld;
                     stk.push(sp, swap ? left : right);
@@ -332,7 +341,8 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                 bool finished = false;
                 if (tri_test(org, dir, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v)) {
                     // src/scene/BVH.cpp:139 (closest) / :93 (any)
-                    if (t > 0.0001f && (ANY_HIT || t < h.t)) {
+                    const bool in_range = ANY_HIT ? (!BOUNDED || !(tfar < inf) || t < tfar) : (t < h.t);
+                    if (t > 0.0001f && in_range) {
                         h.t = t; h.u = u; h.v = v;
                         h.id1 = __float_as_int(c.y);
                         h.id0 = __float_as_int(c.z);

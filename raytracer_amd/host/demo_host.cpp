@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 3; ++k) materials[m].diffuse_color[k] = mats[4 * m + k];
         materials[m].roughness = mats[4 * m + 3];
         materials[m].texture = -1;
+        materials[m].glossy = RT_GLOSSY_NONE;
     }
     std::vector<rt_light> lights(hdr[3]);
     for (uint32_t l = 0; l < hdr[3]; ++l) {
