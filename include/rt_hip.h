@@ -184,6 +184,11 @@ int rt_trace_closest(rt_ctx* ctx, uint32_t n, const float* rays_soa, float* dist
                      int32_t* id1, float* u, float* v);
 /* BVH::occluded (src/scene/BVH.cpp:63-127): status[i] = 1 if anything is hit. */
 int rt_trace_occluded(rt_ctx* ctx, uint32_t n, const float* rays_soa, int32_t* status);
+/* The same with a far bound per ray: only hits with 1e-4 < dist < tmax[i]
+ * occlude (tmax = +inf is rt_trace_occluded).  The reference's shadow rays are
+ * unbounded (src/cpu/PathTracer.cpp:101); the bound belongs to the area
+ * lights, whose samples lie at a finite distance. */
+int rt_trace_occluded_bounded(rt_ctx* ctx, uint32_t n, const float* rays_soa, const float* tmax, int32_t* status);
 
 /* The same two with every buffer already in device memory (HBM-resident
  * inputs; the benchmark path).  Launches on the context's stream; `repeat`

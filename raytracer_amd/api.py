@@ -74,7 +74,7 @@ EXPORTS = [
     "rt_read_film", "rt_film_slab", "rt_copy_film_slab", "rt_unpack_slabs", "rt_trace_closest",
     "rt_trace_occluded", "rt_trace_closest_dev", "rt_trace_occluded_dev", "rt_get_bvh", "rt_get_stats",
     "rt_synchronize", "rt_version", "rt_lbvh_host", "rt_morton3d", "rt_last_trace_ms", "rt_slab_floats", "rt_pack_slab",
-    "rt_read_primary_duv",
+    "rt_read_primary_duv", "rt_trace_occluded_bounded",
 ]
 
 
@@ -112,6 +112,7 @@ def load_library():
     lib.rt_unpack_slabs.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, C.c_uint64, fp]
     lib.rt_trace_closest.argtypes = [vp, C.c_uint32, fp, fp, ip, ip, fp, fp]
     lib.rt_trace_occluded.argtypes = [vp, C.c_uint32, fp, ip]
+    lib.rt_trace_occluded_bounded.argtypes = [vp, C.c_uint32, fp, fp, ip]
     lib.rt_trace_closest_dev.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint32]
     lib.rt_trace_occluded_dev.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32]
     lib.rt_get_bvh.argtypes = [vp, up, fp, ip, ip, ip, ip, ip]
@@ -254,6 +255,15 @@ class Context:
         n = rays.shape[1]
         st = np.empty(n, np.int32)
         self._check(self._lib.rt_trace_occluded(self._h, n, _fptr(rays), _iptr(st)))
+        return st
+
+    def trace_occluded_bounded(self, rays: np.ndarray, tmax: np.ndarray) -> np.ndarray:
+        rays = np.ascontiguousarray(rays, np.float32)
+        tmax = np.ascontiguousarray(tmax, np.float32)
+        n = rays.shape[1]
+        assert tmax.shape == (n,)
+        st = np.empty(n, np.int32)
+        self._check(self._lib.rt_trace_occluded_bounded(self._h, n, _fptr(rays), _fptr(tmax), _iptr(st)))
         return st
 
     def trace_closest_dev(self, n: int, d_rays: int, d_t: int, d_id0: int, d_id1: int, d_u: int, d_v: int, repeat: int = 1):

@@ -239,12 +239,19 @@ int launch_closest(rt_ctx* c, uint32_t n, const float* d_rays, float* d_t, int32
     return RT_OK;
 }
 
-int launch_occluded(rt_ctx* c, uint32_t n, const float* d_rays, int32_t* d_status, uint32_t repeat) {
+int launch_occluded(rt_ctx* c, uint32_t n, const float* d_rays, int32_t* d_status, uint32_t repeat, const float* d_tmax = nullptr) {
     if (repeat == 0) repeat = 1;
     if (int r = ensure_deferred(c, n)) return r;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     for (uint32_t r = 0; r < repeat; ++r) {
         HIP_TRY(c, hipMemsetAsync(c->d_work, 0, sizeof(TraceWork), c->stream));
+        if (d_tmax) {
+            hipLaunchKernelGGL(k_trace_occluded_bounded<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, d_tmax,
+                               n, n, c->d_work, c->d_deferred, d_status);
+            hipLaunchKernelGGL(k_trace_occluded_bounded<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, d_tmax, n,
+                               n, c->d_work, c->d_deferred, d_status);
+            continue;
+        }
         hipLaunchKernelGGL(k_trace_occluded<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
                            c->d_deferred, d_status);
         hipLaunchKernelGGL(k_trace_occluded<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
@@ -951,6 +958,21 @@ int rt_trace_occluded(rt_ctx* c, uint32_t n, const float* rays, int32_t* status)
     if (r) return r;
     HIP_TRY(c, hipMemcpy(c->d_tr_rays, rays, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
     r = launch_occluded(c, n, c->d_tr_rays, reinterpret_cast<int32_t*>(c->d_tr_out), 1);
+    if (r) return r;
+    HIP_TRY(c, hipMemcpy(status, c->d_tr_out, (size_t)n * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_trace_occluded_bounded(rt_ctx* c, uint32_t n, const float* rays, const float* tmax, int32_t* status) {
+    if (!c || !rays || !tmax || !status) return RT_ERR_ARG;
+    if (n == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r = ensure_trace_staging(c, n + n / 6 + 1);   // room for the tmax plane behind the six ray planes
+    if (r) return r;
+    float* d_tmax = c->d_tr_rays + (size_t)n * 6;
+    HIP_TRY(c, hipMemcpy(c->d_tr_rays, rays, (size_t)n * 6 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(d_tmax, tmax, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    r = launch_occluded(c, n, c->d_tr_rays, reinterpret_cast<int32_t*>(c->d_tr_out), 1, d_tmax);
     if (r) return r;
     HIP_TRY(c, hipMemcpy(status, c->d_tr_out, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RT_OK;

@@ -417,6 +417,27 @@ __global__ __launch_bounds__(RT_TBLOCK) void k_extend(TraceScene sc, const float
 
 // Any hit over a ray set (the batch form of BVH::occluded); status[i] = 1
 // when something is hit.
+// Any hit in front of a per-ray far bound (rays plane 6 = tmax): the shadow
+// rays the area lights send.
+template <bool EXACT>
+__global__ __launch_bounds__(RT_TBLOCK) void k_trace_occluded_bounded(TraceScene sc, const float* __restrict__ rays, const float* __restrict__ tmax,
+                                                                     uint32_t stride, uint32_t n, TraceWork* __restrict__ work,
+                                                                     uint32_t* __restrict__ deferred, int32_t* __restrict__ status) {
+    __shared__ int32_t s_stack[RT_STACK_LDS * RT_TBLOCK];
+    __shared__ __attribute__((aligned(16))) char s_top[RT_TOP_BYTES];
+    const TopTree top = stage_top_tree(sc.nodes, sc.n_nodes, s_top);
+    const uint32_t count = EXACT ? work->n_deferred : n;
+    const size_t st = stride;
+    trace_persistent<true, EXACT, true>(
+        sc, count, work, deferred, s_stack, top,
+        [&](uint32_t i, f3& org, f3& dir, float& tfar) {
+            org = mk3(rays[i], rays[st + i], rays[2 * st + i]);
+            dir = mk3(rays[3 * st + i], rays[4 * st + i], rays[5 * st + i]);
+            tfar = tmax[i];
+        },
+        [&](uint32_t i, const HitRec& h) { status[i] = (h.id1 >= 0) ? 1 : 0; });
+}
+
 template <bool EXACT>
 __global__ __launch_bounds__(RT_TBLOCK) void k_trace_occluded(TraceScene sc, const float* __restrict__ rays, uint32_t stride, uint32_t n,
                                                              TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,

@@ -26,6 +26,23 @@ def _render_pair(s, W, H, depth, seed, passes, **kw):
     return film, ref, cnt, st
 
 
+def test_bounded_any_hit_bit_exact(atrium_small):
+    ctx, orc = Context(atrium_small, 64, 64), OracleScene(atrium_small)
+    inc = scenes.incoherent_rays(atrium_small, 100000, seed=21)
+    t = orc.intersect(inc)[0]
+    rng = np.random.default_rng(0)
+    # bounds around the first hit, far beyond it, tiny, infinite
+    tmax = np.where(np.isfinite(t), t, 10.0).astype(np.float32) * rng.choice(np.array([0.5, 0.999, 1.0, 1.001, 3.0], np.float32), t.size)
+    tmax[::7] = np.inf
+    tmax[1::7] = 1e-5
+    got, ref = ctx.trace_occluded_bounded(inc, tmax), orc.occluded_bounded(inc, tmax)
+    assert np.array_equal(got, ref)
+    assert 0.1 < got.mean() < 0.9
+    unb = ctx.trace_occluded(inc)
+    assert np.array_equal(got[::7], unb[::7]) and not got[1::7].any()
+    ctx.close()
+
+
 def test_area_light_film():
     s = scenes.cornell_area()
     film, ref, cnt, st = _render_pair(s, 96, 96, 4, 0, 4)

@@ -102,6 +102,17 @@ def main():
         out["sponza_textured_1080p_d8"] = {"gpu_untextured_16spp": g0, "gpu_textured_16spp": g1, "cpu_oracle_480x270_2spp": c2,
                                            "agreement_480x270": agree(f2, r2), "finite": bool(np.isfinite(film4).all())}
         print("tex", json.dumps(out["sponza_textured_1080p_d8"]), flush=True)
+    if "n4" in which:
+        # C3's scene with the GGX lobe on every model and a ceiling panel of two area lights added
+        sp = scenes.sponza_class()
+        panel = scenes.area_quad((-6, 14.5, -3), (6, 14.5, -3), (6, 14.5, 3), (-6, 14.5, 3), (60.0, 55.0, 45.0))
+        sg = scenes.with_glossy(scenes.replace(sp, lights=sp.lights + panel), scenes.GLOSSY_GGX)
+        film, g1 = gpu_render(sg, 1920, 1080, 8, 16)
+        f2, g2 = gpu_render(sg, 480, 270, 8, 2, seed=4)
+        r2, c2 = cpu_render(sg, 480, 270, 8, 2, seed=4)
+        out["sponza_ggx_area_1080p_d8"] = {"n_lights": len(sg.lights), "gpu_16spp": g1, "cpu_oracle_480x270_2spp": c2,
+                                           "agreement_480x270": agree(f2, r2), "finite": bool(np.isfinite(film).all())}
+        print("n4", json.dumps(out["sponza_ggx_area_1080p_d8"]), flush=True)
     json.dump(out, open(out_path, "w"), indent=1)
 
 
