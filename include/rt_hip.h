@@ -128,6 +128,8 @@ typedef struct rt_stats {
     float last_trace_ms;       /* device time of the last rt_trace_* kernel (HIP events) */
     float last_render_ms;      /* device time of the last rt_render call */
     float bvh_build_ms;        /* LBVH build (GPU or host) including its uploads, wall */
+    uint64_t exact_closest_rays; /* of closest_rays / shadow_rays: rays whose operands the fast box test cannot */
+    uint64_t exact_shadow_rays;  /* decide like the reference's selects, re-traced by the exact follow-up launch */
 } rt_stats;
 
 /* Replaces Integrator::Integrator (src/cpu/Integrator.cpp:7-15): builds the

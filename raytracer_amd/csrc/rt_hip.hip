@@ -24,6 +24,7 @@ thread_local std::string g_create_error;
 struct EnvTables {
     float4* img = nullptr;
     float *cond_func = nullptr, *cond_cdf = nullptr, *cond_int = nullptr, *marg_cdf = nullptr;
+    int32_t *cond_guide = nullptr, *marg_guide = nullptr;
 };
 
 }  // namespace
@@ -81,7 +82,7 @@ struct rt_ctx {
     ShadowQueue sq[2]{};                   // by bounce parity
     float* vpos[2] = {nullptr, nullptr};   // shaded-vertex positions, by bounce parity
     uint32_t* d_pass_deferred_b = nullptr; // deferred list of the shadow launches
-    unsigned long long* d_raystats = nullptr;  // [0] closest, [1] shadow
+    unsigned long long* d_raystats = nullptr;  // [0] closest, [1] shadow, [2] / [3] of those, rays re-traced by the exact follow-up launches
     TraceWork* d_work = nullptr;               // work counters of the rt_trace_* launches
     uint32_t* d_deferred = nullptr;            // rays handed to the exact follow-up launch (rt_trace_*)
     uint32_t deferred_cap = 0;
@@ -159,6 +160,19 @@ float build_cdf(const float* func, int n, float* cdf) {
     return func_int;
 }
 
+// Guide table of a CDF with n+1 entries: guide[b] = number of entries <= b/n,
+// b = 0..n.  The partition point findInterval looks for (src/scene/Common.hpp:13-25)
+// is non-decreasing in u, so for u in bucket b it lies between two guide
+// entries and the search only has to cover that stretch.
+void build_guide(const float* cdf, int n, int32_t* guide) {
+    int p = 0;
+    for (int b = 0; b <= n; ++b) {
+        const float u = (float)b / (float)n;
+        while (p <= n && cdf[p] <= u) ++p;
+        guide[b] = p;
+    }
+}
+
 // EnvLight's constructor, src/lights/EnvLight.cpp:8-26.  The glm::mat3 there
 // is filled column-major from a row-major literal, so the luminance row it
 // applies is (0.3575761, 0.7151522, 0.1191920); the table image is H wide
@@ -180,7 +194,12 @@ int build_env(rt_ctx* c, const rt_light& src, DevLight& dst, EnvTables& tab) {
     }
     for (int v = 0; v < W; ++v) cint[v] = build_cdf(&table[(size_t)v * H], H, &cdf[(size_t)v * (H + 1)]);
     float mint = build_cdf(cint.data(), W, mcdf.data());
+    std::vector<int32_t> cguide((size_t)W * (H + 1)), mguide(W + 1);
+    for (int v = 0; v < W; ++v) build_guide(&cdf[(size_t)v * (H + 1)], H, &cguide[(size_t)v * (H + 1)]);
+    build_guide(mcdf.data(), W, mguide.data());
     int r;
+    if ((r = dev_upload(c, &tab.cond_guide, cguide.data(), cguide.size()))) return r;
+    if ((r = dev_upload(c, &tab.marg_guide, mguide.data(), mguide.size()))) return r;
     if ((r = dev_upload(c, &tab.img, reinterpret_cast<const float4*>(src.env_rgba), (size_t)W * H))) return r;
     if ((r = dev_upload(c, &tab.cond_func, table.data(), table.size()))) return r;
     if ((r = dev_upload(c, &tab.cond_cdf, cdf.data(), cdf.size()))) return r;
@@ -190,6 +209,7 @@ int build_env(rt_ctx* c, const rt_light& src, DevLight& dst, EnvTables& tab) {
     dst.img = tab.img;
     dst.cond_func = tab.cond_func; dst.cond_cdf = tab.cond_cdf; dst.cond_int = tab.cond_int;
     dst.marg_cdf = tab.marg_cdf; dst.marg_int = mint;
+    dst.cond_guide = tab.cond_guide; dst.marg_guide = tab.marg_guide;
     return RT_OK;
 }
 
@@ -305,28 +325,27 @@ int run_pass(rt_ctx* c) {
         if (d == 0 && c->n_textures && c->n_local_tiles)
             hipLaunchKernelGGL(k_quad_duv, dim3(c->n_local_tiles), dim3(RT_BLOCK), 0, c->stream, c->pb, c->d_tri_attr, c->d_duv, c->tile,
                                (float)c->params.width, (float)c->params.height);
-        uint32_t* sqc = c->d_counts + (D + 1) + d;
         // shade(d) overwrites the parity-p buffers that shadow/accumulate(d-2) read
         if (L > 0 && d >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_acc[d - 2], 0));
         if (c->any_glossy)
             hipLaunchKernelGGL(k_shade<true>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
-                               qout, cnt_out, c->sq[p], sqc);
+                               qout, cnt_out, c->sq[p], c->d_raystats + 1);
         else
             hipLaunchKernelGGL(k_shade<false>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
-                               qout, cnt_out, c->sq[p], sqc);
+                               qout, cnt_out, c->sq[p], c->d_raystats + 1);
         if (L > 0) {
             HIP_TRY(c, hipEventRecord(c->ev_shade[d], c->stream));
             HIP_TRY(c, hipStreamWaitEvent(c->stream_b, c->ev_shade[d], 0));
             TraceWork* w = work + D + d;
             if (c->any_area) {   // shadow rays towards area lights stop at the light
-                hipLaunchKernelGGL((k_shadow<false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], sqc, w,
+                hipLaunchKernelGGL((k_shadow<false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], L, qin, cnt_in, w,
                                    c->d_pass_deferred_b, c->d_raystats + 1);
-                hipLaunchKernelGGL((k_shadow<true, true>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], sqc,
+                hipLaunchKernelGGL((k_shadow<true, true>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], L, qin, cnt_in,
                                    w, c->d_pass_deferred_b, c->d_raystats + 1);
             } else {
-                hipLaunchKernelGGL((k_shadow<false, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], sqc, w,
+                hipLaunchKernelGGL((k_shadow<false, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], L, qin, cnt_in, w,
                                    c->d_pass_deferred_b, c->d_raystats + 1);
-                hipLaunchKernelGGL((k_shadow<true, false>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], sqc,
+                hipLaunchKernelGGL((k_shadow<true, false>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], L, qin, cnt_in,
                                    w, c->d_pass_deferred_b, c->d_raystats + 1);
             }
             hipLaunchKernelGGL(k_accumulate, dim3(gshade), dim3(RT_BLOCK), 0, c->stream_b, pbd, c->sq[p], L, qin, cnt_in);
@@ -730,8 +749,6 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         for (int p = 0; p < 2; ++p) {
             ShadowQueue& q = c->sq[p];
             q.cap = (uint32_t)cap;
-            if ((r = dev_alloc(c, &q.slot, cap))) return r;
-            if ((r = dev_alloc(c, &q.light, cap))) return r;
             if ((r = dev_alloc(c, &q.dir, 3 * cap))) return r;
             q.tmax = nullptr;
             if (c->any_area && (r = dev_alloc(c, &q.tmax, cap))) return r;
@@ -742,8 +759,8 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         if ((r = dev_alloc(c, &c->d_pass_deferred_b, cap))) return r;
     }
     if ((r = dev_alloc(c, &c->d_work, 1))) return r;
-    if ((r = dev_alloc(c, &c->d_raystats, 2))) return r;
-    HIP_TRY(c, hipMemset(c->d_raystats, 0, 2 * sizeof(unsigned long long)));
+    if ((r = dev_alloc(c, &c->d_raystats, 4))) return r;
+    HIP_TRY(c, hipMemset(c->d_raystats, 0, 4 * sizeof(unsigned long long)));
     HIP_TRY(c, hipDeviceSynchronize());
     return RT_OK;
 }
@@ -1025,11 +1042,13 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     if (!c || !out) return RT_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    unsigned long long rs[2] = {0, 0};
+    unsigned long long rs[4] = {0, 0, 0, 0};
     HIP_TRY(c, hipMemcpy(rs, c->d_raystats, sizeof rs, hipMemcpyDeviceToHost));
     memset(out, 0, sizeof *out);
     out->closest_rays = rs[0];
     out->shadow_rays = rs[1];
+    out->exact_closest_rays = rs[2];
+    out->exact_shadow_rays = rs[3];
     out->passes = c->frames;
     out->n_nodes = c->n_ref_nodes;
     out->n_triangles = c->n_triangles;

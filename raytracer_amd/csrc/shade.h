@@ -30,6 +30,8 @@ struct DevLight {
     const float* cond_int;   // [W] (also the marginal's func)
     const float* marg_cdf;   // [W+1]
     float marg_int;
+    const int32_t* cond_guide;  // [W][H+1]: entries of the row's CDF that are <= b/H
+    const int32_t* marg_guide;  // [W+1]
     // area: one emissive triangle, radiance (ix, iy, iz) on the side of n = cross(p1-p0, p2-p0)
     float p0[3], p1[3], p2[3], n[3];
     float area;
@@ -100,6 +102,31 @@ RT_DEV uint32_t wave_append(bool pred, uint32_t* counter) {
         base = __shfl(base, leader);
     }
     return base + prefix;
+}
+
+// The same for a whole workgroup: one atomic per workgroup.  Same-address
+// atomics retire at roughly 90 per microsecond on this part, so a queue that
+// every wave appends to by itself caps a kernel at ~6 G lanes/s.  Must be
+// reached by every thread of the workgroup; s_cnt holds RT_BLOCK/64 + 1 words.
+RT_DEV uint32_t block_append(bool pred, uint32_t* counter, uint32_t* s_cnt) {
+    constexpr uint32_t WAVES = RT_BLOCK / 64;
+    unsigned long long m = __ballot(pred);
+    const uint32_t lane = __lane_id(), w = threadIdx.x >> 6;
+    if (lane == 0) s_cnt[w] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t k = 0; k < WAVES; ++k) {
+            uint32_t c = s_cnt[k];
+            s_cnt[k] = tot;
+            tot += c;
+        }
+        s_cnt[WAVES] = tot ? atomicAdd(counter, tot) : 0u;
+    }
+    __syncthreads();
+    uint32_t r = s_cnt[WAVES] + s_cnt[w] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    __syncthreads();
+    return r;
 }
 
 // --------------------------------------------------------------- sampling
@@ -481,9 +508,31 @@ RT_DEV int find_interval_cdf(const float* cdf, int size, float u) {
     }
     return (int)clampf((float)(first - 1), 0.f, (float)(size - 2));
 }
+// The same interval found through a guide table (guide[b] = number of CDF
+// entries <= b/n): the CDF is non-decreasing, so the partition point of
+// `cdf[i] <= u` is unique and lies between the guide entries one bucket below
+// and two above floor(u*n) (the margin absorbs the rounding of u*n and b/n).
+// Two or three dependent loads instead of log2(n).
+RT_DEV int find_interval_guided(const float* cdf, const int32_t* guide, int n, float u) {
+    int b = (int)(u * (float)n);
+    b = b < 0 ? 0 : (b > n - 1 ? n - 1 : b);
+    const int lo = guide[b > 0 ? b - 1 : 0];
+    const int hi = guide[b + 2 < n ? b + 2 : n];
+    // entries below lo are <= u and entries from hi on are > u by construction
+    int first = lo, len = hi - lo;
+    while (len > 0) {
+        int half = len >> 1, middle = first + half;
+        if (cdf[middle] <= u) {
+            first = middle + 1;
+            len -= half + 1;
+        } else
+            len = half;
+    }
+    return (int)clampf((float)(first - 1), 0.f, (float)(n - 1));
+}
 // src/samplers/Distributions.cpp:26-35
-RT_DEV float dist1d_sample(const float* cdf, const float* func, float funcInt, int n, float u, float& pdf, int& off) {
-    int offset = find_interval_cdf(cdf, n + 1, u);
+RT_DEV float dist1d_sample(const float* cdf, const float* func, const int32_t* guide, float funcInt, int n, float u, float& pdf, int& off) {
+    int offset = find_interval_guided(cdf, guide, n, u);
     off = offset;
     float c0 = cdf[offset], c1 = cdf[offset + 1];
     float du = u - c0;
@@ -600,8 +649,9 @@ RT_DEV f3 light_sample(const DevLight& l, f3 p, f2 u, f3& in, float& pdf, float&
     // Distribution2D::sampleContinuous, src/samplers/Distributions.cpp:60-68
     float pdf0, pdf1;
     int v, dummy;
-    float d1 = dist1d_sample(l.marg_cdf, l.cond_int, l.marg_int, l.W, u.y, pdf1, v);
-    float d0 = dist1d_sample(l.cond_cdf + (size_t)v * (l.H + 1), l.cond_func + (size_t)v * l.H, l.cond_int[v], l.H, u.x, pdf0, dummy);
+    float d1 = dist1d_sample(l.marg_cdf, l.cond_int, l.marg_guide, l.marg_int, l.W, u.y, pdf1, v);
+    float d0 = dist1d_sample(l.cond_cdf + (size_t)v * (l.H + 1), l.cond_func + (size_t)v * l.H, l.cond_guide + (size_t)v * (l.H + 1),
+                             l.cond_int[v], l.H, u.x, pdf0, dummy);
     float mapPdf = pdf0 * pdf1;
     pdf = 0.0f;
     in = mk3(0.f, 0.f, 0.f);
@@ -745,19 +795,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_quad_duv(PathBuffers pb, const flo
     }
 }
 
-// Shadow rays of one bounce, all lights in one queue: entry k names the path
-// slot and the light, and carries the ray direction (the origin is the
-// path's shaded vertex).  What the ray would add is kept per (light, slot):
-// the two contributions the reference adds one after the other once the ray
-// is found unoccluded (src/cpu/PathTracer.cpp:107 or :109, then :123), and a
-// state byte: 0 no ray, 1 ray queued, 2 ray found unoccluded.
+// Shadow rays of one bounce.  Nothing is compacted: everything is indexed by
+// e = light * n_slots + slot, and the work items of k_shadow are the pairs
+// (light, entry of the bounce's path queue).  Per entry: the ray direction
+// (the origin is the path's shaded vertex), its far bound, the two
+// contributions the reference adds one after the other once the ray is found
+// unoccluded (src/cpu/PathTracer.cpp:107 or :109, then :123), and a state
+// byte: 0 no ray, 1 ray pending, 2 ray found unoccluded.
 struct ShadowQueue {
-    uint32_t* slot;    // [cap]
-    uint32_t* light;   // [cap]
     float* dir;        // 3 planes of cap
     float* tmax;       // [cap] far bound of each ray, or null when the scene has no area light
-    float* contrib;    // 6 planes of cap, indexed light * n_slots + slot
-    uint8_t* state;    // [cap], indexed light * n_slots + slot
+    float* contrib;    // 6 planes of cap
+    uint8_t* state;    // [cap]
     uint32_t cap;      // n_lights * n_slots
 };
 
@@ -771,16 +820,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
                                                     uint32_t pass, const uint32_t* __restrict__ queue,
                                                     const uint32_t* __restrict__ d_count, uint32_t* __restrict__ next_queue,
                                                     uint32_t* __restrict__ next_count, ShadowQueue sq,
-                                                    uint32_t* __restrict__ sq_count) {
+                                                    unsigned long long* __restrict__ shadow_ray_counter) {
+    __shared__ uint32_t s_cnt[RT_BLOCK / 64 + 1];
     const uint32_t count = *d_count;
-    const uint32_t gtid = blockIdx.x * RT_BLOCK + threadIdx.x;
     const uint32_t gsize = gridDim.x * RT_BLOCK;
-    const uint32_t lane = gtid & 63u;
     const size_t n = pb.n;
     const int L = sc.n_lights;
-    // every lane of a wave runs the same number of iterations (ballots inside)
-    for (uint32_t base = gtid - lane; base < count; base += gsize) {
-        uint32_t i = base + lane;
+    uint32_t n_emit = 0;   // shadow rays this wave queued (wave-uniform)
+    // every thread of a workgroup runs the same number of iterations (barriers inside)
+    for (uint32_t bbase = blockIdx.x * RT_BLOCK; bbase < count; bbase += gsize) {
+        uint32_t i = bbase + threadIdx.x;
         bool valid = i < count;
         uint32_t s = valid ? queue[i] : 0u;
         bool hit = false;
@@ -915,14 +964,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
             // a shadow ray that could only add exact zeros changes nothing whether
             // or not it is occluded (L + 0 == L), so it is not traced
             emit = emit && !(is_zero3(C) && is_zero3(C2));
-            uint32_t k = wave_append(emit, sq_count);
+            n_emit += (uint32_t)__popcll(__ballot(emit));
             if (valid) sq.state[(size_t)l * n + s] = emit ? 1 : 0;
             if (emit) {
                 const size_t cap = sq.cap, e = (size_t)l * n + s;
-                sq.slot[k] = s;
-                sq.light[k] = (uint32_t)l;
-                sq.dir[k] = in.x; sq.dir[cap + k] = in.y; sq.dir[2 * cap + k] = in.z;
-                if (sq.tmax) sq.tmax[k] = tmax;
+                sq.dir[e] = in.x; sq.dir[cap + e] = in.y; sq.dir[2 * cap + e] = in.z;
+                if (sq.tmax) sq.tmax[e] = tmax;
                 sq.contrib[e] = C.x; sq.contrib[cap + e] = C.y; sq.contrib[2 * cap + e] = C.z;
                 sq.contrib[3 * cap + e] = C2.x; sq.contrib[4 * cap + e] = C2.y; sq.contrib[5 * cap + e] = C2.z;
             }
@@ -946,8 +993,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
                 pb.rays[3 * n + s] = nextDir.x; pb.rays[4 * n + s] = nextDir.y; pb.rays[5 * n + s] = nextDir.z;
             }
         }
-        uint32_t k = wave_append(alive, next_count);
+        uint32_t k = block_append(alive, next_count, s_cnt);
         if (alive) next_queue[k] = s;
+    }
+    // ray statistics: one atomic per workgroup
+    if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = n_emit;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (uint32_t k = 0; k < RT_BLOCK / 64; ++k) tot += s_cnt[k];
+        if (tot) atomicAdd(shadow_ray_counter, (unsigned long long)tot);
     }
 }
 
@@ -956,35 +1011,50 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
 // unoccluded ray only marks its (light, slot) state; k_accumulate then adds
 // the contributions in the reference's order.
 template <bool EXACT, bool BOUNDED>
-__global__ __launch_bounds__(RT_TBLOCK) void k_shadow(TraceScene ts, PathBuffers pb, ShadowQueue q, const uint32_t* __restrict__ d_count,
+__global__ __launch_bounds__(RT_TBLOCK) void k_shadow(TraceScene ts, PathBuffers pb, ShadowQueue q, int n_lights,
+                                                     const uint32_t* __restrict__ queue, const uint32_t* __restrict__ d_count,
                                                      TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
                                                      unsigned long long* __restrict__ ray_counter) {
     __shared__ int32_t s_stack[RT_STACK_LDS * RT_TBLOCK];
     __shared__ __attribute__((aligned(16))) char s_top[RT_TOP_BYTES];
     const TopTree top = stage_top_tree(ts.nodes, ts.n_nodes, s_top);
-    const uint32_t count = EXACT ? work->n_deferred : *d_count;
+    const uint32_t paths = *d_count;
+    // work item j = (light j / paths, path-queue entry j % paths)
+    const uint32_t count = EXACT ? work->n_deferred : paths * (uint32_t)n_lights;
     const size_t n = pb.n, cap = q.cap;
-    if (!EXACT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)count);
-    auto mark = [&](uint32_t i, const HitRec& h) {
-        if (h.id1 < 0) q.state[(size_t)q.light[i] * n + q.slot[i]] = 2;
+    if (EXACT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter + 2, (unsigned long long)count);
+    auto entry = [&](uint32_t j, uint32_t& s) -> size_t {
+        const uint32_t l = j / paths;
+        s = queue[j - l * paths];
+        return (size_t)l * n + s;
+    };
+    auto mark = [&](uint32_t j, const HitRec& h) {
+        uint32_t s;
+        if (h.id1 < 0) q.state[entry(j, s)] = 2;
     };
     if constexpr (BOUNDED) {
         trace_persistent<true, EXACT, true>(
             ts, count, work, deferred, s_stack, top,
-            [&](uint32_t i, f3& org, f3& dir, float& tfar) {
-                uint32_t s = q.slot[i];
+            [&](uint32_t j, f3& org, f3& dir, float& tfar) -> bool {
+                uint32_t s;
+                const size_t e = entry(j, s);
+                if (q.state[e] != 1) return false;
                 org = mk3(pb.vpos[s], pb.vpos[n + s], pb.vpos[2 * n + s]);
-                dir = mk3(q.dir[i], q.dir[cap + i], q.dir[2 * cap + i]);
-                tfar = q.tmax[i];
+                dir = mk3(q.dir[e], q.dir[cap + e], q.dir[2 * cap + e]);
+                tfar = q.tmax[e];
+                return true;
             },
             mark);
     } else {
         trace_persistent<true, EXACT, false>(
             ts, count, work, deferred, s_stack, top,
-            [&](uint32_t i, f3& org, f3& dir) {
-                uint32_t s = q.slot[i];
+            [&](uint32_t j, f3& org, f3& dir) -> bool {
+                uint32_t s;
+                const size_t e = entry(j, s);
+                if (q.state[e] != 1) return false;
                 org = mk3(pb.vpos[s], pb.vpos[n + s], pb.vpos[2 * n + s]);
-                dir = mk3(q.dir[i], q.dir[cap + i], q.dir[2 * cap + i]);
+                dir = mk3(q.dir[e], q.dir[cap + e], q.dir[2 * cap + e]);
+                return true;
             },
             mark);
     }

@@ -189,8 +189,9 @@ struct TraceWork {
 };
 
 // Persistent traversal of `count` work items.  `load(i, org, dir)` fetches
-// work item i; `done(i, hit)` consumes its result (hit.id1 < 0 = nothing
-// hit).
+// work item i and returns false when the item holds no ray (it is then
+// dropped without a call to `done`); `done(i, hit)` consumes a ray's result
+// (hit.id1 < 0 = nothing hit).
 //
 // EXACT = false is the main launch: box tests use hardware min/max, and a
 // ray whose origin or inverse direction is not finite and moderate (where
@@ -258,13 +259,15 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     uint32_t i = c_next + r;
                     if (EXACT) i = deferred[i];
                     item = i;
-                    if constexpr (BOUNDED) load(i, org, dir, tfar);
-                    else load(i, org, dir);
+                    bool present;
+                    if constexpr (BOUNDED) present = load(i, org, dir, tfar);
+                    else present = load(i, org, dir);
                     inv = make_invdir(dir);
                     h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
                     float rd;
                     // root box test of src/scene/BVH.cpp:51-53
-                    if (slab_test(org, inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2], rd)) {
+                    if (!present) {
+                    } else if (slab_test(org, inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2], rd)) {
                         const bool tame = EXACT || (sc.tame && moderate(org.x) && moderate(org.y) && moderate(org.z) &&
                                                     moderate(inv.x) && moderate(inv.y) && moderate(inv.z));
                         if (tame) {
@@ -374,12 +377,14 @@ __global__ __launch_bounds__(RT_TBLOCK) void k_trace_closest(TraceScene sc, cons
     const TopTree top = stage_top_tree(sc.nodes, sc.n_nodes, s_top);
     if (!EXACT && ray_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)n);
     const uint32_t count = EXACT ? work->n_deferred : n;
+    if (EXACT && ray_counter && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter + 2, (unsigned long long)count);
     const size_t st = stride;
     trace_persistent<false, EXACT>(
         sc, count, work, deferred, s_stack, top,
-        [&](uint32_t i, f3& org, f3& dir) {
+        [&](uint32_t i, f3& org, f3& dir) -> bool {
             org = mk3(rays[i], rays[st + i], rays[2 * st + i]);
             dir = mk3(rays[3 * st + i], rays[4 * st + i], rays[5 * st + i]);
+            return true;
         },
         [&](uint32_t i, const HitRec& h) {
             o_t[i] = h.t; o_id0[i] = h.id0; o_id1[i] = h.id1; o_u[i] = h.u; o_v[i] = h.v;
@@ -400,14 +405,15 @@ __global__ __launch_bounds__(RT_TBLOCK) void k_extend(TraceScene sc, const float
     __shared__ __attribute__((aligned(16))) char s_top[RT_TOP_BYTES];
     const TopTree top = stage_top_tree(sc.nodes, sc.n_nodes, s_top);
     const uint32_t count = EXACT ? work->n_deferred : *d_count;
-    if (!EXACT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter, (unsigned long long)count);
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter + (EXACT ? 2 : 0), (unsigned long long)count);
     const size_t st = stride;
     trace_persistent<false, EXACT>(
         sc, count, work, deferred, s_stack, top,
-        [&](uint32_t i, f3& org, f3& dir) {
+        [&](uint32_t i, f3& org, f3& dir) -> bool {
             uint32_t s = queue[i];
             org = mk3(rays[s], rays[st + s], rays[2 * st + s]);
             dir = mk3(rays[3 * st + s], rays[4 * st + s], rays[5 * st + s]);
+            return true;
         },
         [&](uint32_t i, const HitRec& h) {
             uint32_t s = queue[i];
@@ -430,10 +436,11 @@ __global__ __launch_bounds__(RT_TBLOCK) void k_trace_occluded_bounded(TraceScene
     const size_t st = stride;
     trace_persistent<true, EXACT, true>(
         sc, count, work, deferred, s_stack, top,
-        [&](uint32_t i, f3& org, f3& dir, float& tfar) {
+        [&](uint32_t i, f3& org, f3& dir, float& tfar) -> bool {
             org = mk3(rays[i], rays[st + i], rays[2 * st + i]);
             dir = mk3(rays[3 * st + i], rays[4 * st + i], rays[5 * st + i]);
             tfar = tmax[i];
+            return true;
         },
         [&](uint32_t i, const HitRec& h) { status[i] = (h.id1 >= 0) ? 1 : 0; });
 }
@@ -449,9 +456,10 @@ __global__ __launch_bounds__(RT_TBLOCK) void k_trace_occluded(TraceScene sc, con
     const size_t st = stride;
     trace_persistent<true, EXACT>(
         sc, count, work, deferred, s_stack, top,
-        [&](uint32_t i, f3& org, f3& dir) {
+        [&](uint32_t i, f3& org, f3& dir) -> bool {
             org = mk3(rays[i], rays[st + i], rays[2 * st + i]);
             dir = mk3(rays[3 * st + i], rays[4 * st + i], rays[5 * st + i]);
+            return true;
         },
         [&](uint32_t i, const HitRec& h) { status[i] = (h.id1 >= 0) ? 1 : 0; });
 }

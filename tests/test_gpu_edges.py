@@ -170,3 +170,27 @@ def test_no_frame_scene_matches_oracle(cornell):
     err = np.abs(film[..., :3].astype(np.float64) - ref[..., :3])
     assert np.sqrt((err ** 2).mean()) / np.sqrt((ref[..., :3].astype(np.float64) ** 2).mean()) < 1e-4
     ctx.close()
+
+
+@pytest.mark.parametrize("size", [(100, 37), (7, 5), (256, 128)])
+def test_env_sampling_sparse_maps(size):
+    """Environment maps whose CDFs have long flat stretches and odd sizes: the
+    guided interval search must land on the interval the reference's binary
+    search finds (src/scene/Common.hpp:13-25, src/samplers/Distributions.cpp:26-35)."""
+    W, H = size
+    rng = np.random.default_rng(W)
+    env = np.zeros((H, W, 4), np.float32)
+    env[..., 3] = 1
+    for _ in range(max(3, W * H // 200)):
+        env[rng.integers(0, H // 2 + 1), rng.integers(0, W), :3] = rng.uniform(5, 50, 3)
+    base = scenes.cornell_box()
+    s = scenes.replace(base, lights=[scenes.Light(scenes.LIGHT_ENV, intensity=np.ones(3, np.float32), env=env)])
+    ref, _ = OracleScene(s).render(s.camera, 48, 48, 3, 6, 3, threads=4)
+    ctx = Context(s, 48, 48, max_depth=3, seed=6)
+    ctx.set_camera(s.camera)
+    ctx.render(3)
+    film = ctx.read_film()
+    ctx.close()
+    assert ref[..., :3].max() > 0
+    err = np.abs(film[..., :3] - ref[..., :3])
+    assert float(np.sqrt((err ** 2).mean()) / np.sqrt((ref[..., :3] ** 2).mean())) < 1e-4
