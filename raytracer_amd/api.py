@@ -56,7 +56,7 @@ class rt_scene_desc(C.Structure):
 class rt_params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("max_depth", C.c_int32), ("tile_size", C.c_int32),
                 ("seed", C.c_uint64), ("device", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("batch", C.c_uint32)]
 
 
 RT_FLAG_HOST_BVH = 1
@@ -146,7 +146,7 @@ class Context:
     """One rt_ctx: a scene resident on one MI355X plus this rank's share of the film."""
 
     def __init__(self, scene: Scene, width: int, height: int, max_depth: int = 4, seed: int = 0, device: int = 0,
-                 rank: int = 0, world: int = 1, tile_size: int = 64, use_frame: bool = True, host_bvh: bool = False):
+                 rank: int = 0, world: int = 1, tile_size: int = 64, use_frame: bool = True, host_bvh: bool = False, batch: int = 0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.width, self.height, self.world, self.rank, self.tile_size = width, height, world, rank, tile_size
@@ -191,7 +191,7 @@ class Context:
         d.n_models, d.materials = s.n_models, mats
         d.n_lights, d.lights = len(s.lights), lights
         d.n_textures, d.textures = len(s.textures), textures
-        p = rt_params(width, height, max_depth, tile_size, seed, device, rank, world, RT_FLAG_HOST_BVH if host_bvh else 0)
+        p = rt_params(width, height, max_depth, tile_size, seed, device, rank, world, RT_FLAG_HOST_BVH if host_bvh else 0, batch)
         rc = self._lib.rt_create(C.byref(d), C.byref(p), C.byref(self._h))
         if rc != 0:
             raise RtError(rc, self._lib.rt_last_error(None).decode())

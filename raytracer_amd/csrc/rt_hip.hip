@@ -40,7 +40,9 @@ struct rt_ctx {
 
     rt_params params{};
     int tile = 64, tiles_x = 0, tiles_y = 0;
-    uint32_t n_local_tiles = 0, n_slots = 0, n_valid = 0;
+    uint32_t n_local_tiles = 0, n_slots = 0, n_valid = 0;   // of one pass
+    uint32_t batch = 1;        // passes traced together
+    uint32_t n_total = 0;      // n_slots * batch: slots of the path state
 
     // geometry
     LbvhResult bvh;            // host build (RT_FLAG_HOST_BVH)
@@ -286,10 +288,12 @@ int launch_occluded(rt_ctx* c, uint32_t n, const float* d_rays, int32_t* d_statu
     return RT_OK;
 }
 
-// One sample pass: the GPU form of Integrator::update (src/cpu/Integrator.cpp:26-67).
-int run_pass(rt_ctx* c) {
+// nb sample passes traced as one wavefront: the GPU form of nb calls of
+// Integrator::update (src/cpu/Integrator.cpp:26-67).  Slot b * n_slots + s is
+// film slot s of pass (frames + b).
+int run_pass(rt_ctx* c, uint32_t nb) {
     const int D = c->params.max_depth, L = c->n_lights;
-    const uint32_t n = c->n_slots;
+    const uint32_t n = c->n_total;
     const uint32_t pass = (uint32_t)c->frames;
     const uint64_t seed_mixed = [&] {
         uint64_t z = c->params.seed + 0x9E3779B97F4A7C15ull;
@@ -297,11 +301,13 @@ int run_pass(rt_ctx* c) {
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
         return z ^ (z >> 31);
     }();
-    HIP_TRY(c, hipMemcpyAsync(c->d_counts, c->d_counts_init, c->n_counts * sizeof(uint32_t), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_counts, c->d_counts_init + (size_t)(nb - 1) * c->n_counts, c->n_counts * sizeof(uint32_t),
+                              hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_pass_work, 0, c->n_pass_work * sizeof(TraceWork), c->stream));
-    const uint32_t gslots = (n + RT_BLOCK - 1) / RT_BLOCK;
-    hipLaunchKernelGGL(k_generate, dim3(gslots), dim3(RT_BLOCK), 0, c->stream, c->pb, c->cam);
-    const uint32_t gtrace = grid_for(c, c->n_valid);
+    const uint32_t live = nb * c->n_slots;
+    const uint32_t gslots = (live + RT_BLOCK - 1) / RT_BLOCK;
+    hipLaunchKernelGGL(k_generate, dim3(gslots), dim3(RT_BLOCK), 0, c->stream, c->pb, c->cam, live);
+    const uint32_t gtrace = grid_for(c, nb * c->n_valid);
     const uint32_t gshade = std::min<uint32_t>(gslots, (uint32_t)c->num_cu * 8u);
     // Two chains share the GPU: the main stream runs extend(d) -> shade(d),
     // stream_b runs shadow(d) -> accumulate(d).  shadow(d) only needs what
@@ -323,7 +329,7 @@ int run_pass(rt_ctx* c) {
                            work + d, c->d_pass_deferred, c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v,
                            c->d_raystats);
         if (d == 0 && c->n_textures && c->n_local_tiles)
-            hipLaunchKernelGGL(k_quad_duv, dim3(c->n_local_tiles), dim3(RT_BLOCK), 0, c->stream, c->pb, c->d_tri_attr, c->d_duv, c->tile,
+            hipLaunchKernelGGL(k_quad_duv, dim3(nb * c->n_local_tiles), dim3(RT_BLOCK), 0, c->stream, c->pb, c->d_tri_attr, c->d_duv, c->tile,
                                (float)c->params.width, (float)c->params.height);
         // shade(d) overwrites the parity-p buffers that shadow/accumulate(d-2) read
         if (L > 0 && d >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_acc[d - 2], 0));
@@ -354,9 +360,9 @@ int run_pass(rt_ctx* c) {
         qin = qout;
     }
     if (L > 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_acc[D - 1], 0));
-    hipLaunchKernelGGL(k_film, dim3(gslots), dim3(RT_BLOCK), 0, c->stream, c->pb, (float)c->frames);
+    hipLaunchKernelGGL(k_film, dim3((c->n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->pb, (float)c->frames, nb);
     HIP_TRY(c, hipGetLastError());
-    c->frames++;
+    c->frames += nb;
     return RT_OK;
 }
 
@@ -702,9 +708,30 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         }
     }
     c->n_valid = (uint32_t)q0.size();
-    const size_t n = c->n_slots;
-    if ((r = dev_upload(c, &c->d_slot_pixel, c->h_slot_pixel.data(), n))) return r;
-    if ((r = dev_upload(c, &c->d_q0, q0.data(), q0.size()))) return r;
+    // ---- passes traced together: as many as asked for (default 4) within a
+    // path-state budget of 24 GiB and 32-bit entry indices
+    {
+        const uint64_t L1 = (uint64_t)std::max<uint32_t>(1, sd->n_lights);
+        const uint64_t per_slot = 160 + 82 * L1;   // bytes of path state and shadow entries per slot
+        uint64_t S = pr->batch ? pr->batch : 4;
+        const uint64_t one = std::max<uint64_t>(1, (uint64_t)c->n_slots);
+        S = std::min<uint64_t>(S, std::max<uint64_t>(1, (24ull << 30) / (per_slot * one)));
+        S = std::min<uint64_t>(S, std::max<uint64_t>(1, 0x7FFFFFFFull / (L1 * one)));
+        S = std::min<uint64_t>(S, 64);
+        c->batch = (uint32_t)S;
+        c->n_total = c->batch * c->n_slots;
+    }
+    const size_t n = c->n_total;
+    {
+        std::vector<uint32_t> sp(n ? n : 1, 0xFFFFFFFFu), qa;
+        qa.reserve((size_t)c->batch * q0.size());
+        for (uint32_t b = 0; b < c->batch; ++b) {
+            std::copy(c->h_slot_pixel.begin(), c->h_slot_pixel.end(), sp.begin() + (size_t)b * c->n_slots);
+            for (uint32_t s : q0) qa.push_back(b * c->n_slots + s);
+        }
+        if ((r = dev_upload(c, &c->d_slot_pixel, sp.data(), n))) return r;
+        if ((r = dev_upload(c, &c->d_q0, qa.data(), qa.size()))) return r;
+    }
     if ((r = dev_alloc(c, &c->d_q[0], n))) return r;
     if ((r = dev_alloc(c, &c->d_q[1], n))) return r;
     if ((r = dev_alloc(c, &c->d_q[2], n))) return r;
@@ -720,11 +747,12 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     if ((r = dev_alloc(c, &c->vpos[1], 3 * n))) return r;
     c->pb.vpos = c->vpos[0];
     if ((r = dev_alloc(c, &c->pb.status, n))) return r;
-    if ((r = dev_alloc(c, &c->pb.film, n))) return r;
-    HIP_TRY(c, hipMemset(c->pb.film, 0, (n ? n : 1) * sizeof(float4)));
+    if ((r = dev_alloc(c, &c->pb.film, (size_t)c->n_slots))) return r;
+    HIP_TRY(c, hipMemset(c->pb.film, 0, (c->n_slots ? c->n_slots : 1) * sizeof(float4)));
     HIP_TRY(c, hipMemset(c->pb.rays, 0, (n ? n : 1) * 6 * sizeof(float)));
     c->pb.slot_pixel = c->d_slot_pixel;
     c->pb.n = (uint32_t)n;
+    c->pb.n1 = c->n_slots ? c->n_slots : 1;
     if (c->n_textures) {
         if ((r = dev_alloc(c, &c->d_duv, n))) return r;
         HIP_TRY(c, hipMemset(c->d_duv, 0, (n ? n : 1) * sizeof(float4)));
@@ -736,8 +764,9 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     c->n_pass_work = (uint32_t)(2 * D);
     if ((r = dev_alloc(c, &c->d_pass_work, c->n_pass_work))) return r;
     if ((r = dev_alloc(c, &c->d_pass_deferred, n))) return r;
-    std::vector<uint32_t> init(c->n_counts, 0u);
-    init[0] = c->n_valid;
+    // one template of the queue counters per batch size: entry 0 = paths the pass starts with
+    std::vector<uint32_t> init((size_t)c->n_counts * c->batch, 0u);
+    for (uint32_t b = 0; b < c->batch; ++b) init[(size_t)b * c->n_counts] = (b + 1) * c->n_valid;
     if ((r = dev_upload(c, &c->d_counts_init, init.data(), init.size()))) return r;
     if ((r = dev_alloc(c, &c->d_counts, c->n_counts))) return r;
     {
@@ -814,9 +843,11 @@ int rt_render(rt_ctx* c, uint32_t n_passes) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (c->n_slots == 0) { c->frames += n_passes; return RT_OK; }
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
-    for (uint32_t p = 0; p < n_passes; ++p) {
-        int r = run_pass(c);
+    for (uint32_t p = 0; p < n_passes;) {
+        const uint32_t nb = std::min(c->batch, n_passes - p);
+        int r = run_pass(c, nb);
         if (r) return r;
+        p += nb;
     }
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipEventSynchronize(c->ev1));

@@ -49,8 +49,9 @@ struct PathBuffers {
     float* vpos;        // 3 planes: position of the vertex being shaded
     uint32_t* status;   // 1 = the primary ray hit (film takes the running mean)
     const uint32_t* slot_pixel;  // y*W+x, or 0xFFFFFFFF for a slot outside the film
-    float4* film;
-    uint32_t n;         // slots
+    float4* film;       // n1 entries: one per film pixel slot
+    uint32_t n;         // slots = plane stride: n1 * (passes traced together)
+    uint32_t n1;        // slots of one pass; slot s belongs to pass s / n1 of the batch and to film slot s % n1
 };
 
 // One mip level of a diffuse map inside the shared texel buffer.
@@ -699,9 +700,9 @@ RT_DEV uint32_t dim_bounce(int d, int L, int k) { return (uint32_t)(d * (4 * L +
 
 // ---------------------------------------------------------------- kernels
 // Camera rays, src/cpu/PathTracer.cpp:43-52; also clears the per-pass state.
-__global__ __launch_bounds__(RT_BLOCK) void k_generate(PathBuffers pb, CameraK cam) {
+__global__ __launch_bounds__(RT_BLOCK) void k_generate(PathBuffers pb, CameraK cam, uint32_t count) {
     uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (s >= pb.n) return;
+    if (s >= count) return;
     uint32_t pix = pb.slot_pixel[s];
     pb.status[s] = 0;
     size_t n = pb.n;
@@ -817,7 +818,7 @@ struct ShadowQueue {
 // found unoccluded, then the BSDF bounce.
 template <bool GLOSSY>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene sc, int depth, int max_depth, uint64_t seed_mixed,
-                                                    uint32_t pass, const uint32_t* __restrict__ queue,
+                                                    uint32_t first_pass, const uint32_t* __restrict__ queue,
                                                     const uint32_t* __restrict__ d_count, uint32_t* __restrict__ next_queue,
                                                     uint32_t* __restrict__ next_count, ShadowQueue sq,
                                                     unsigned long long* __restrict__ shadow_ray_counter) {
@@ -845,7 +846,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
                 // src/cpu/PathTracer.cpp:61-65: the film takes the summed le, no accumulation
                 f3 Lm = mk3(0.f, 0.f, 0.f);
                 for (int l = 0; l < L; ++l) Lm = Lm + light_le(sc.lights[l], dir);
-                pb.film[s] = make_float4(Lm.x, Lm.y, Lm.z, 1.0f);
+                // every pass of a batch writes the same value here (the primary ray does not depend on the pass)
+                pb.film[s % pb.n1] = make_float4(Lm.x, Lm.y, Lm.z, 1.0f);
             }
         }
         BsdfK bsdf;
@@ -857,6 +859,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
         f3 vpos = mk3(0.f, 0.f, 0.f), vn = mk3(0.f, 0.f, 1.f), out = mk3(0.f, 0.f, 1.f);
         f3 beta = mk3(1.f, 1.f, 1.f);
         uint32_t pixel = 0;
+        const uint32_t pass = first_pass + s / pb.n1;
         if (hit) {
             if (depth == 0) pb.status[s] = 1;
             pixel = pb.slot_pixel[s];
@@ -1083,22 +1086,32 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(PathBuffers pb, ShadowQ
 }
 
 // Film update, src/cpu/PathTracer.cpp:148-157: running mean over passes for
-// pixels whose primary ray hit.  In place: the reference's ping-pong pair
-// only ever reads the previous value of the same pixel.
-__global__ __launch_bounds__(RT_BLOCK) void k_film(PathBuffers pb, float frames) {
-    uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x;
-    if (s >= pb.n || pb.status[s] != 1) return;
-    size_t n = pb.n;
-    f3 c = mk3(pb.L[s], pb.L[n + s], pb.L[2 * n + s]);
-    if (frames != 0.0f) {
-        float4 p = pb.film[s];
-        f3 prev = mk3(p.x, p.y, p.z);
-        prev = prev * frames;
-        prev = prev + c;
-        prev = prev / (frames + 1.f);
-        c = prev;
+// pixels whose primary ray hit.  The passes of a batch are folded in one
+// after the other, in pass order, so the film is the one n_passes separate
+// updates would leave.  In place: the reference's ping-pong pair only ever
+// reads the previous value of the same pixel.
+__global__ __launch_bounds__(RT_BLOCK) void k_film(PathBuffers pb, float first_frames, uint32_t n_passes) {
+    uint32_t s1 = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (s1 >= pb.n1) return;
+    const size_t n = pb.n;
+    float4 p = pb.film[s1];
+    bool any = false;
+    float frames = first_frames;
+    for (uint32_t b = 0; b < n_passes; ++b, frames += 1.0f) {
+        const size_t s = (size_t)b * pb.n1 + s1;
+        if (pb.status[s] != 1) continue;
+        any = true;
+        f3 c = mk3(pb.L[s], pb.L[n + s], pb.L[2 * n + s]);
+        if (frames != 0.0f) {
+            f3 prev = mk3(p.x, p.y, p.z);
+            prev = prev * frames;
+            prev = prev + c;
+            prev = prev / (frames + 1.f);
+            c = prev;
+        }
+        p = make_float4(c.x, c.y, c.z, 1.0f);
     }
-    pb.film[s] = make_float4(c.x, c.y, c.z, 1.0f);
+    if (any) pb.film[s1] = p;
 }
 
 }  // namespace rt

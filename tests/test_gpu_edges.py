@@ -194,3 +194,25 @@ def test_env_sampling_sparse_maps(size):
     assert ref[..., :3].max() > 0
     err = np.abs(film[..., :3] - ref[..., :3])
     assert float(np.sqrt((err ** 2).mean()) / np.sqrt((ref[..., :3] ** 2).mean())) < 1e-4
+
+
+def test_batched_passes_leave_the_same_film(cornell_env):
+    """rt_render may trace several passes as one wavefront (rt_params.batch);
+    the film must be the one single passes leave, bit for bit, also when the
+    pass count is not a multiple of the batch and for textured scenes."""
+    s = scenes.with_textures(cornell_env, uv_scale=3.0)
+    films = []
+    for batch, chunks in ((1, (5,)), (4, (5,)), (3, (2, 3)), (8, (1, 1, 3))):
+        ctx = Context(s, 50, 38, max_depth=3, seed=9, tile_size=16, batch=batch)
+        ctx.set_camera(s.camera)
+        for n in chunks:
+            ctx.render(n)
+        films.append(ctx.read_film())
+        st = ctx.stats()
+        assert st["passes"] == 5
+        ctx.close()
+    for f in films[1:]:
+        assert np.array_equal(_bits(f), _bits(films[0]))
+    ref, _ = OracleScene(s).render(s.camera, 50, 38, 3, 9, 5, threads=4, tile_size=16)
+    err = np.abs(films[0][..., :3] - ref[..., :3])
+    assert float(np.sqrt((err ** 2).mean()) / np.sqrt((ref[..., :3] ** 2).mean())) < 1e-4
