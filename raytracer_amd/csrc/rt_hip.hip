@@ -708,14 +708,14 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         }
     }
     c->n_valid = (uint32_t)q0.size();
-    // ---- passes traced together: as many as asked for (default 4) within a
-    // path-state budget of 24 GiB and 32-bit entry indices
+    // ---- passes traced together: as many as asked for (default 8) within a
+    // path-state budget of 48 GiB and 32-bit entry indices
     {
         const uint64_t L1 = (uint64_t)std::max<uint32_t>(1, sd->n_lights);
         const uint64_t per_slot = 160 + 82 * L1;   // bytes of path state and shadow entries per slot
-        uint64_t S = pr->batch ? pr->batch : 4;
+        uint64_t S = pr->batch ? pr->batch : 8;
         const uint64_t one = std::max<uint64_t>(1, (uint64_t)c->n_slots);
-        S = std::min<uint64_t>(S, std::max<uint64_t>(1, (24ull << 30) / (per_slot * one)));
+        S = std::min<uint64_t>(S, std::max<uint64_t>(1, (48ull << 30) / (per_slot * one)));
         S = std::min<uint64_t>(S, std::max<uint64_t>(1, 0x7FFFFFFFull / (L1 * one)));
         S = std::min<uint64_t>(S, 64);
         c->batch = (uint32_t)S;
