@@ -70,18 +70,21 @@ def main():
     n = W * H
     coherent = scenes.camera_rays_numpy(scene.camera, W, H)
     incoherent = scenes.incoherent_rays(scene, n, seed=0x5EED + rank)
-    sets = {"coherent": coherent, "incoherent": incoherent}
-    # one batch = both sets, resident in HBM as one SoA buffer of 2n rays: a step is ONE launch over it
+    # the rays a path tracer sends after the primary hit, captured from depth-2 passes of the tracer itself
+    bounce = scenes.bounce_rays(scene, W, H, n, seed=0x5EED + rank, device=local_rank)
+    sets = {"coherent": coherent, "incoherent": incoherent, "bounce": bounce}
+    NS = len(sets)
+    # one batch = the three sets, resident in HBM as one SoA buffer of 3n rays: a step is ONE launch over it
     # (a launch costs about one worst-case ray latency, ~0.2 ms, whatever its size)
-    both = np.ascontiguousarray(np.concatenate([coherent, incoherent], axis=1))
+    both = np.ascontiguousarray(np.concatenate([sets[k] for k in sets], axis=1))
     d_both = torch.from_numpy(both).to(dev)
     d_rays = {k: torch.from_numpy(v).to(dev) for k, v in sets.items()}
-    out_f = torch.empty((3, 2 * n), dtype=torch.float32, device=dev)
-    out_i = torch.empty((2, 2 * n), dtype=torch.int32, device=dev)
+    out_f = torch.empty((3, NS * n), dtype=torch.float32, device=dev)
+    out_i = torch.empty((2, NS * n), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
     def step(times=None):
-        ctx.trace_closest_dev(2 * n, d_both.data_ptr(), out_f[0].data_ptr(), out_i[0].data_ptr(), out_i[1].data_ptr(),
+        ctx.trace_closest_dev(NS * n, d_both.data_ptr(), out_f[0].data_ptr(), out_i[0].data_ptr(), out_i[1].data_ptr(),
                               out_f[1].data_ptr(), out_f[2].data_ptr(), 1)
         if times is not None:
             times.append(ctx.last_trace_ms())
@@ -105,16 +108,16 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    rays_per_step = 2 * n * world
+    rays_per_step = NS * n * world
     mrays = rays_per_step * args.steps / elapsed / 1e6
 
-    # hit ids of the last launch (its incoherent half) for the parity spot check below
-    gpu_id1 = out_i[1, n:].cpu().numpy().copy()
-    gpu_t = out_f[0, n:].cpu().numpy().copy()
+    # hit ids and distances of the last timed launch for the full-size parity check below
+    gpu_id1 = out_i[1].cpu().numpy().copy()
+    gpu_t = out_f[0].cpu().numpy().copy()
 
     # diagnostics outside the timed region: each set launched by itself
-    set_ms = {"coherent": float("nan"), "incoherent": float("nan")}
-    for k in () if args.no_set_diagnostics else ("coherent", "incoherent"):
+    set_ms = {k: float("nan") for k in sets}
+    for k in () if args.no_set_diagnostics else tuple(sets):
         ctx.trace_closest_dev(n, d_rays[k].data_ptr(), out_f[0].data_ptr(), out_i[0].data_ptr(), out_i[1].data_ptr(),
                               out_f[1].data_ptr(), out_f[2].data_ptr(), 5)
         set_ms[k] = ctx.last_trace_ms()
@@ -161,19 +164,21 @@ def main():
         orc = OracleScene(scene)
         counts = {}
         cpu_s = 0.0
-        cpu_reps = 4  # about 20 CPU-seconds at 16 threads
-        for k in ("coherent", "incoherent"):
+        cpu_reps = 3  # about 20 CPU-seconds at 16 threads
+        parity = {"rays": NS * n, "id_mismatches": 0, "dist_bit_mismatches": 0, "per_set": {}}
+        for j, k in enumerate(sets):
             for rep in range(cpu_reps):
                 c0 = time.perf_counter()
                 rt, rid0, rid1, ru, rv, cnt = orc.intersect(sets[k], counters=True, threads=threads)
                 cpu_s += time.perf_counter() - c0
             counts[k] = cnt
-            if k == "incoherent":
-                parity = {"set": "incoherent", "rays": n,
-                          "id_mismatches": int((rid1 != gpu_id1).sum()),
-                          "dist_bit_mismatches": int((rt.view(np.uint32) != gpu_t.view(np.uint32)).sum())}
-        cpu_baseline = {"value": cpu_reps * 2 * n / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-                        "sample": f"both full ray sets ({2*n} rays) x {cpu_reps}, oracle closest hit, {threads} threads, {cpu_s:.1f} s wall"}
+            bad_id = int((rid1 != gpu_id1[j * n:(j + 1) * n]).sum())
+            bad_t = int((rt.view(np.uint32) != gpu_t[j * n:(j + 1) * n].view(np.uint32)).sum())
+            parity["per_set"][k] = {"id_mismatches": bad_id, "dist_bit_mismatches": bad_t, "hit_fraction": float((rid1 >= 0).mean())}
+            parity["id_mismatches"] += bad_id
+            parity["dist_bit_mismatches"] += bad_t
+        cpu_baseline = {"value": cpu_reps * NS * n / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                        "sample": f"the full ray sets ({NS*n} rays) x {cpu_reps}, oracle closest hit, {threads} threads, {cpu_s:.1f} s wall"}
         if render is not None:
             # the oracle's integrator on a bounded sample of the render workload: one full-resolution pass
             rw, rh = W, H
@@ -195,19 +200,19 @@ def main():
                 traffic = None
         roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                    "bytes_per_launch": tot_bytes, "avg_launch_ms": launch_ms, "rays_per_launch": 2 * n,
+                    "bytes_per_launch": tot_bytes, "avg_launch_ms": launch_ms, "rays_per_launch": NS * n,
                     "per_set": {k: {"n_inner_per_ray": counts[k]["n_inner"] / n, "n_tri_per_ray": counts[k]["n_tri"] / n,
                                     "bytes_per_ray": algorithmic_bytes(n, counts[k]["n_inner"], counts[k]["n_tri"]) / n,
                                     "launched_alone_ms": set_ms[k],
                                     "launched_alone_mrays_per_sec": n / set_ms[k] / 1e3} for k in counts}}
 
     line = {
-        "kernel_ms": {"both_sets_one_launch": float(np.mean(kernel_ms)), **{k + "_alone": v for k, v in set_ms.items()}},
+        "kernel_ms": {"all_sets_one_launch": float(np.mean(kernel_ms)), **{k + "_alone": v for k, v in set_ms.items()}},
         "metric": "Mrays/sec (closest-hit, whole node)", "value": mrays, "unit": "Mrays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"primary-ray closest hit, sponza_class ({scene.n_triangles} triangles) {W}x{H}: "
-                               f"coherent + incoherent sets of {n} rays each per GPU per step, one launch",
+                               f"coherent + incoherent + bounce sets of {n} rays each per GPU per step, one launch",
                    "rays_per_step": rays_per_step, "bvh": "reference LBVH, 1 triangle per leaf"},
         "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "render": render,
     }

@@ -163,6 +163,11 @@ int rt_read_film(rt_ctx* ctx, float* rgba_out);
  * (src/cpu/PathTracer.cpp:83-90), width*height*4 floats of this rank's pixels;
  * zero where the primary ray missed or the scene has no textures. */
 int rt_read_primary_duv(rt_ctx* ctx, float* duv_out);
+/* Diagnostic / workload capture: the rays the last rt_render traced at its
+ * deepest bounce (the `ray` of src/cpu/PathTracer.cpp:134-135 at d = max_depth-2),
+ * in slot order, as 6 SoA planes of `cap` floats; *n_out = how many there were
+ * (at most cap are copied; cap = 0 only asks for the count). */
+int rt_read_last_bounce_rays(rt_ctx* ctx, float* rays_soa, uint32_t cap, uint32_t* n_out);
 
 /* This rank's packed tile slab on the device: n_tiles*tile*tile*4 floats,
  * tiles in increasing global tile index.  For gathering the film across ranks. */

@@ -66,6 +66,8 @@ def lib():
     L.orc_brute_force.argtypes = [vp, C.c_uint64, fp, fp, ip]
     L.orc_render.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, fp, u64p,
                              C.c_int, fp]
+    L.orc_capture_bounce_rays.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_int, C.c_int, fp,
+                                          C.POINTER(C.c_uint8)]
     L.orc_camera_rays.argtypes = [fp, C.c_int, C.c_int, fp]
     L.orc_morton3d.restype = C.c_uint32
     L.orc_morton3d.argtypes = [C.c_float] * 3
@@ -211,6 +213,23 @@ class OracleScene:
         self._L.orc_render(self._h, _f(c), W, H, max_depth, seed, first_pass, n_passes, threads, _f(film), cnt, tile_size,
                             None if duv is None else _f(duv))
         return film, {"closest": cnt[0], "shadow": cnt[1]}
+
+    def bounce_rays(self, cam, W, H, n, depth=0, max_depth=4, seed=0, threads=8):
+        """(6, n) f32: bounce rays leaving the `depth`-th shaded vertex, gathered pass by pass until n are found."""
+        out, have, p = np.empty((6, n), np.float32), 0, 0
+        rays = np.empty((6, W * H), np.float32)
+        flags = np.empty(W * H, np.uint8)
+        c = cam.packed()
+        while have < n:
+            self._L.orc_capture_bounce_rays(self._h, _f(c), W, H, max_depth, seed, p, threads, depth, _f(rays),
+                                            flags.ctypes.data_as(C.POINTER(C.c_uint8)))
+            idx = np.nonzero(flags)[0][: n - have]
+            if idx.size == 0 and p > 64:
+                raise RuntimeError("the scene produces no bounce rays")
+            out[:, have:have + idx.size] = rays[:, idx]
+            have += idx.size
+            p += 1
+        return out
 
     def texture_level(self, t, level):
         w, h = C.c_int32(), C.c_int32()

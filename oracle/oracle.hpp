@@ -1108,6 +1108,17 @@ struct RenderCounters {
     std::atomic<uint64_t> closest{0}, shadow{0};
 };
 
+// Test/bench hook: records the bounce ray each pixel traces after its
+// `depth`-th shaded vertex (depth 0 = the ray leaving the primary hit).
+// rays: 6 planes (ox oy oz dx dy dz) of n floats indexed by pixel; flags[pixel]
+// = 1 where a ray was recorded.
+struct RayCapture {
+    float* rays = nullptr;
+    uint8_t* flags = nullptr;
+    int depth = 0;
+    size_t n = 0;
+};
+
 // Random-number slots of one path vertex at depth d with L lights: per
 // light 2 (light sample) + 2 (the BSDF sample of the non-delta branch), then
 // 2 for the bounce.  Fixed slots so that a skipped draw does not shift later
@@ -1156,7 +1167,7 @@ inline BSDF computeBSDF(const Scene& s, const Vertex& v, int model) {
 // passes already accumulated; film is W*H RGBA32F, updated in place (the
 // reference's ping-pong pair reads the previous value of the same pixel only).
 inline void shadePixel(const Scene& s, int x, int y, int W, int maxDepth, uint64_t seed, uint32_t pass, float frames, float* film,
-                       Ray ray, Vertex vertex, BSDF bsdf, RenderCounters* rc) {
+                       Ray ray, Vertex vertex, BSDF bsdf, RenderCounters* rc, const RayCapture* cap = nullptr) {
     const int L = (int)s.lights.size();
     const uint32_t pixel = (uint32_t)(y * W + x);
     float* out4 = film + (size_t)pixel * 4;
@@ -1203,6 +1214,12 @@ inline void shadePixel(const Scene& s, int x, int y, int W, int maxDepth, uint64
         if (is_zero(bsdfColor) || nextPDF == 0.0f) break;
         threshold = threshold * (bsdfColor * std::fabs(dot(nextDir, vertex.normal)) / nextPDF);
         ray = Ray(vertex.pos, nextDir);
+        if (cap && cap->depth == d) {
+            const size_t n = cap->n;
+            cap->rays[pixel] = ray.org.x; cap->rays[n + pixel] = ray.org.y; cap->rays[2 * n + pixel] = ray.org.z;
+            cap->rays[3 * n + pixel] = ray.dir.x; cap->rays[4 * n + pixel] = ray.dir.y; cap->rays[5 * n + pixel] = ray.dir.z;
+            cap->flags[pixel] = 1;
+        }
         nClosest++;
         RayHit hit = s.bvh.intersect(ray);
         if (hit.status) {
@@ -1232,7 +1249,8 @@ inline void shadePixel(const Scene& s, int x, int y, int W, int maxDepth, uint64
 // missed (or lies outside the film) contributes the UV of an earlier quad --
 // zero at the start of a tile (sVertex's members are taken as zero-initialised).
 inline void computeTile(const Scene& s, const Camera& cam, int startX, int startY, int W, int H, int tileSize, int maxDepth,
-                        uint64_t seed, uint32_t pass, float frames, float* film, RenderCounters* rc, float* duvOut = nullptr) {
+                        uint64_t seed, uint32_t pass, float frames, float* film, RenderCounters* rc, float* duvOut = nullptr,
+                        const RayCapture* cap = nullptr) {
     bool statusBlock[4] = {false, false, false, false};
     Vertex vertexBlock[4];
     int modelBlock[4] = {0, 0, 0, 0};
@@ -1284,7 +1302,7 @@ inline void computeTile(const Scene& s, const Camera& cam, int startX, int start
                         o[0] = dUVx.x; o[1] = dUVx.y; o[2] = dUVy.x; o[3] = dUVy.y;
                     }
                     BSDF bsdf = computeBSDF(s, vertex, modelBlock[yB * 2 + xB], dUVx, dUVy);
-                    shadePixel(s, x, y, W, maxDepth, seed, pass, frames, film, raysBlock[yB * 2 + xB], vertex, bsdf, rc);
+                    shadePixel(s, x, y, W, maxDepth, seed, pass, frames, film, raysBlock[yB * 2 + xB], vertex, bsdf, rc, cap);
                 }
             }
         }
@@ -1296,7 +1314,7 @@ inline void computeTile(const Scene& s, const Camera& cam, int startX, int start
 // height for its y extent, where the reference's width only adds empty tiles).
 inline void renderPass(const Scene& s, const Camera& cam, int W, int H, int maxDepth, uint64_t seed,
                        uint32_t pass, float frames, float* film, int threads, RenderCounters* rc, int tileSize = 64,
-                       float* duvOut = nullptr) {
+                       float* duvOut = nullptr, const RayCapture* cap = nullptr) {
     int tx = (W + tileSize - 1) / tileSize, ty = (H + tileSize - 1) / tileSize;
     std::atomic<int> tileCurr{0};
     int tileCount = tx * ty;
@@ -1304,7 +1322,7 @@ inline void renderPass(const Scene& s, const Camera& cam, int W, int H, int maxD
         for (;;) {
             int t = tileCurr++;
             if (t >= tileCount) break;
-            computeTile(s, cam, (t % tx) * tileSize, (t / tx) * tileSize, W, H, tileSize, maxDepth, seed, pass, frames, film, rc, duvOut);
+            computeTile(s, cam, (t % tx) * tileSize, (t / tx) * tileSize, W, H, tileSize, maxDepth, seed, pass, frames, film, rc, duvOut, cap);
         }
     };
     if (threads <= 1) { worker(); return; }

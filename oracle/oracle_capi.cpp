@@ -184,6 +184,22 @@ void orc_render(const orc_scene* o, const float* camera, int W, int H, int max_d
 }
 
 // Camera rays of src/cpu/PathTracer.cpp:43-52 for the whole film, row-major.
+// One pass rendered only to record the bounce rays leaving the `depth`-th
+// shaded vertex of every pixel (rays: 6 planes of W*H floats, flags: W*H bytes).
+void orc_capture_bounce_rays(const orc_scene* o, const float* camera, int W, int H, int max_depth, uint64_t seed, uint32_t pass,
+                             int threads, int depth, float* rays, uint8_t* flags) {
+    Camera cam;
+    cam.pos = {camera[0], camera[1], camera[2]};
+    cam.right = {camera[3], camera[4], camera[5]};
+    cam.up = {camera[6], camera[7], camera[8]};
+    cam.forward = {camera[9], camera[10], camera[11]};
+    std::vector<float> film((size_t)W * H * 4, 0.f);
+    std::memset(flags, 0, (size_t)W * H);
+    RayCapture cap;
+    cap.rays = rays; cap.flags = flags; cap.depth = depth; cap.n = (size_t)W * H;
+    renderPass(o->s, cam, W, H, max_depth, seed, pass, 0.0f, film.data(), threads, nullptr, 64, nullptr, &cap);
+}
+
 void orc_camera_rays(const float* camera, int W, int H, float* rays) {
     Camera cam;
     cam.pos = {camera[0], camera[1], camera[2]};

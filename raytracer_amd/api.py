@@ -74,7 +74,7 @@ EXPORTS = [
     "rt_read_film", "rt_film_slab", "rt_copy_film_slab", "rt_unpack_slabs", "rt_trace_closest",
     "rt_trace_occluded", "rt_trace_closest_dev", "rt_trace_occluded_dev", "rt_get_bvh", "rt_get_stats",
     "rt_synchronize", "rt_version", "rt_lbvh_host", "rt_morton3d", "rt_last_trace_ms", "rt_slab_floats", "rt_pack_slab",
-    "rt_read_primary_duv", "rt_trace_occluded_bounded",
+    "rt_read_primary_duv", "rt_trace_occluded_bounded", "rt_read_last_bounce_rays",
 ]
 
 
@@ -107,6 +107,7 @@ def load_library():
     lib.rt_render.argtypes = [vp, C.c_uint32]
     lib.rt_read_film.argtypes = [vp, fp]
     lib.rt_read_primary_duv.argtypes = [vp, fp]
+    lib.rt_read_last_bounce_rays.argtypes = [vp, fp, C.c_uint32, up]
     lib.rt_film_slab.argtypes = [vp, C.POINTER(vp), up, C.POINTER(C.c_uint64)]
     lib.rt_copy_film_slab.argtypes = [vp, vp, C.c_uint64]
     lib.rt_unpack_slabs.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, C.c_uint64, fp]
@@ -231,6 +232,15 @@ class Context:
         """(H, W, 4): dUVx.xy, dUVy.xy of the last pass's primary hits (zero where the ray missed)."""
         out = np.empty((self.height, self.width, 4), np.float32)
         self._check(self._lib.rt_read_primary_duv(self._h, _fptr(out)))
+        return out
+
+    def last_bounce_rays(self) -> np.ndarray:
+        """(6, k) f32: the rays the last render() traced at its deepest bounce."""
+        n = C.c_uint32()
+        self._check(self._lib.rt_read_last_bounce_rays(self._h, None, 0, C.byref(n)))
+        out = np.empty((6, n.value), np.float32)
+        if n.value:
+            self._check(self._lib.rt_read_last_bounce_rays(self._h, _fptr(out), n.value, C.byref(n)))
         return out
 
     def film_slab_info(self) -> Tuple[int, int, int]:

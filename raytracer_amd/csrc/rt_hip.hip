@@ -888,6 +888,30 @@ int rt_read_primary_duv(rt_ctx* c, float* duv_out) {
     return RT_OK;
 }
 
+int rt_read_last_bounce_rays(rt_ctx* c, float* rays_soa, uint32_t cap, uint32_t* n_out) {
+    if (!c || !n_out || (cap && !rays_soa)) return RT_ERR_ARG;
+    *n_out = 0;
+    const int D = c->params.max_depth;
+    if (D < 2 || c->frames == 0 || c->n_total == 0) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint32_t count = 0;
+    HIP_TRY(c, hipMemcpy(&count, c->d_counts + (D - 1), sizeof count, hipMemcpyDeviceToHost));
+    *n_out = count;
+    if (!cap || !count) return RT_OK;
+    const uint32_t take = std::min(count, cap);
+    std::vector<uint32_t> q(take);
+    HIP_TRY(c, hipMemcpy(q.data(), c->d_q[(D - 1) % 3], (size_t)take * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    const size_t n = c->n_total;
+    std::vector<float> rays(6 * n);
+    HIP_TRY(c, hipMemcpy(rays.data(), c->pb.rays, rays.size() * sizeof(float), hipMemcpyDeviceToHost));
+    // the queue is filled in whatever order workgroups finish: hand the rays out in slot order
+    std::sort(q.begin(), q.end());
+    for (uint32_t i = 0; i < take; ++i)
+        for (int k = 0; k < 6; ++k) rays_soa[(size_t)k * cap + i] = rays[(size_t)k * n + q[i]];
+    return RT_OK;
+}
+
 int rt_film_slab(rt_ctx* c, const float** device_ptr, uint32_t* n_tiles, uint64_t* n_floats) {
     if (!c) return RT_ERR_ARG;
     if (device_ptr) *device_ptr = reinterpret_cast<const float*>(c->pb.film);

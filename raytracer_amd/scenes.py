@@ -496,6 +496,29 @@ def incoherent_rays(scene: Scene, n: int, seed: int = 0x5EED) -> np.ndarray:
     return np.ascontiguousarray(np.concatenate([org, d], 0), np.float32)
 
 
+def bounce_rays(scene: Scene, W: int, H: int, n: int, seed: int = 0x5EED, device: int = 0) -> np.ndarray:
+    """(6, n) f32 SoA: the rays a path tracer sends after the primary hit
+    (origins on the surfaces the camera sees, directions sampled from the
+    BSDF), taken from the tracer itself: depth-2 passes at W x H are rendered
+    until n rays have been collected."""
+    from .api import Context
+    ctx = Context(scene, W, H, max_depth=2, seed=seed, device=device, batch=1)
+    ctx.set_camera(scene.camera)
+    out, have = np.empty((6, n), np.float32), 0
+    for _ in range(256):
+        ctx.render(1)
+        r = ctx.last_bounce_rays()
+        k = min(n - have, r.shape[1])
+        out[:, have:have + k] = r[:, :k]
+        have += k
+        if have >= n:
+            break
+    ctx.close()
+    if have < n:
+        raise RuntimeError("the scene yields too few bounce rays")
+    return out
+
+
 def camera_rays_numpy(cam: Camera, W: int, H: int) -> np.ndarray:
     """(6, W*H) f32 SoA of the pinhole rays of src/cpu/PathTracer.cpp:43-52,
     row-major, evaluated in float32 with the same operation order."""

@@ -216,3 +216,28 @@ def test_batched_passes_leave_the_same_film(cornell_env):
     ref, _ = OracleScene(s).render(s.camera, 50, 38, 3, 9, 5, threads=4, tile_size=16)
     err = np.abs(films[0][..., :3] - ref[..., :3])
     assert float(np.sqrt((err ** 2).mean()) / np.sqrt((ref[..., :3] ** 2).mean())) < 1e-4
+
+
+def test_last_bounce_rays_match_oracle(cornell_env):
+    """The workload-capture hook returns the rays the oracle's integrator
+    traces after the primary hit (src/cpu/PathTracer.cpp:134-135): same
+    origins bit for bit, directions up to the ulps of the device sin/cos."""
+    s = cornell_env
+    ctx = Context(s, 40, 30, max_depth=2, seed=3, batch=1)
+    ctx.set_camera(s.camera)
+    ctx.render(1)
+    got = ctx.last_bounce_rays()
+    ctx.close()
+    from oracle.binding import lib as olib
+    o = OracleScene(s)
+    rays = np.empty((6, 1200), np.float32)
+    flags = np.empty(1200, np.uint8)
+    olib().orc_capture_bounce_rays(o._h, s.camera.packed().ctypes.data_as(C.POINTER(C.c_float)), 40, 30, 2, 3, 0, 2, 0,
+                                   rays.ctypes.data_as(C.POINTER(C.c_float)), flags.ctypes.data_as(C.POINTER(C.c_uint8)))
+    ref = rays[:, flags.astype(bool)]
+    assert got.shape == ref.shape and ref.shape[1] > 300
+    # both are in pixel order up to the tile/8x8 slot order of the GPU: sort by origin
+    ko, kr = np.lexsort(got[:3][::-1]), np.lexsort(ref[:3][::-1])
+    assert np.array_equal(_bits(got[:3, ko]), _bits(ref[:3, kr]))
+    assert np.abs(got[3:, ko] - ref[3:, kr]).max() < 1e-5
+    assert scenes.bounce_rays(s, 40, 30, 2000).shape == (6, 2000)
