@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
 // unoccluded ray only marks its (light, slot) state; k_accumulate then adds
 // the contributions in the reference's order.
 template <bool EXACT, bool BOUNDED>
-__global__ __launch_bounds__(RT_TBLOCK) void k_shadow(TraceScene ts, PathBuffers pb, ShadowQueue q, int n_lights,
+__global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_shadow(TraceScene ts, PathBuffers pb, ShadowQueue q, int n_lights,
                                                      const uint32_t* __restrict__ queue, const uint32_t* __restrict__ d_count,
                                                      TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
                                                      unsigned long long* __restrict__ ray_counter) {

@@ -34,7 +34,7 @@ namespace rt {
 
 #define RT_BLOCK 256        // shading kernels
 #ifndef RT_TBLOCK
-#define RT_TBLOCK 512       // traversal kernels: 3 workgroups (24 waves) per CU
+#define RT_TBLOCK 1024      // traversal kernels: 2 workgroups (32 waves) per CU share each top-tree copy
 #endif
 #ifndef RT_STACK_LDS
 #define RT_STACK_LDS 12
@@ -44,6 +44,9 @@ namespace rt {
 #endif
 #define RT_TOP_NODES ((1 << RT_TOP_LEVELS) - 1)
 // vote thresholds (lanes of 64)
+#ifndef RT_LB_WAVES
+#define RT_LB_WAVES , 8      // second launch bound: 8 waves per SIMD, i.e. at most 64 VGPRs
+#endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 20   // refill when at least this many lanes are idle
 #endif
@@ -90,6 +93,48 @@ RT_DEV bool slab_test_fast(f3 org, f3 inv, float bx0, float by0, float bz0, floa
     float tmax = fminf(fmaxf(lox, hix), fminf(fmaxf(loy, hiy), fmaxf(loz, hiz)));
     dist = tmin;
     return (tmin <= tmax) && (tmax > 0.0f);
+}
+
+// (Measured and not used by default, -DRT_PACKED_SLAB: wave64 packed fp32
+// operations issue at half rate on this part, the kernel came out 4 % slower.)
+// Both child boxes of a node at once with packed fp32 arithmetic: the twelve
+// subtractions and the twelve products become six v_pk_add_f32 and six
+// v_pk_mul_f32 (each lane of a packed operation rounds like the scalar one,
+// so the results are those of slab_test_fast bit for bit).  The ray keeps its
+// origin and inverse direction in the three pair orders the node layout asks
+// for: a = (lmin.x lmin.y | lmin.z lmax.x), b = (lmax.y lmax.z | rmin.x rmin.y),
+// c = (rmin.z rmax.x | rmax.y rmax.z).
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct RayPk {
+    v2f o_xy, o_zx, o_yz, i_xy, i_zx, i_yz;
+};
+RT_DEV RayPk make_ray_pk(f3 org, f3 inv) {
+    RayPk r;
+    r.o_xy = (v2f){org.x, org.y}; r.o_zx = (v2f){org.z, org.x}; r.o_yz = (v2f){org.y, org.z};
+    r.i_xy = (v2f){inv.x, inv.y}; r.i_zx = (v2f){inv.z, inv.x}; r.i_yz = (v2f){inv.y, inv.z};
+    return r;
+}
+RT_DEV void slab2_fast_pk(const RayPk& r, float4 a, float4 b, float4 c, bool& ls, float& ld, bool& rs, float& rd) {
+    const v2f t0 = r.i_xy * ((v2f){a.x, a.y} - r.o_xy);   // left  lo.x lo.y
+    const v2f t1 = r.i_zx * ((v2f){a.z, a.w} - r.o_zx);   // left  lo.z hi.x
+    const v2f t2 = r.i_yz * ((v2f){b.x, b.y} - r.o_yz);   // left  hi.y hi.z
+    const v2f t3 = r.i_xy * ((v2f){b.z, b.w} - r.o_xy);   // right lo.x lo.y
+    const v2f t4 = r.i_zx * ((v2f){c.x, c.y} - r.o_zx);   // right lo.z hi.x
+    const v2f t5 = r.i_yz * ((v2f){c.z, c.w} - r.o_yz);   // right hi.y hi.z
+    {
+        const float lox = t0.x, loy = t0.y, loz = t1.x, hix = t1.y, hiy = t2.x, hiz = t2.y;
+        const float tmin = fmaxf(fminf(lox, hix), fmaxf(fminf(loy, hiy), fminf(loz, hiz)));
+        const float tmax = fminf(fmaxf(lox, hix), fminf(fmaxf(loy, hiy), fmaxf(loz, hiz)));
+        ld = tmin;
+        ls = (tmin <= tmax) && (tmax > 0.0f);
+    }
+    {
+        const float lox = t3.x, loy = t3.y, loz = t4.x, hix = t4.y, hiy = t5.x, hiz = t5.y;
+        const float tmin = fmaxf(fminf(lox, hix), fmaxf(fminf(loy, hiy), fminf(loz, hiz)));
+        const float tmax = fminf(fmaxf(lox, hix), fminf(fmaxf(loy, hiy), fmaxf(loz, hiz)));
+        rd = tmin;
+        rs = (tmin <= tmax) && (tmax > 0.0f);
+    }
 }
 
 // Per-lane traversal stack: levels below RT_STACK_LDS in LDS, the rest in
@@ -231,6 +276,9 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
     int32_t cur = 0;
     int sp = 0;
     f3 org = mk3(0.f, 0.f, 0.f), dir = mk3(0.f, 0.f, 1.f), inv = mk3(0.f, 0.f, 1.f);
+#ifdef RT_PACKED_SLAB
+    RayPk pk = make_ray_pk(org, inv);
+#endif
     HitRec h;
     h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
     float tfar = inf;
@@ -263,6 +311,9 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     if constexpr (BOUNDED) present = load(i, org, dir, tfar);
                     else present = load(i, org, dir);
                     inv = make_invdir(dir);
+#ifdef RT_PACKED_SLAB
+                    if (!EXACT) pk = make_ray_pk(org, inv);
+#endif
                     h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
                     float rd;
                     // root box test of src/scene/BVH.cpp:51-53
@@ -301,7 +352,8 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     left = l2.x; right = l2.y;
                     // pins these as LDS reads: without it the compiler folds the two
                     // branches into flat-address loads of a selected pointer
-                    asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(left));
+                    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c.x), "+v"(c.y),
+                                 "+v"(c.z), "+v"(c.w), "+v"(left), "+v"(right));
                 } else {
                     const float4* np = sc.nodes + (size_t)cur * 4;
                     a = np[0]; b = np[1]; c = np[2];
@@ -314,8 +366,12 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     ls = slab_test(org, inv, a.x, a.y, a.z, a.w, b.x, b.y, ld);
                     rs = slab_test(org, inv, b.z, b.w, c.x, c.y, c.z, c.w, rdist);
                 } else {
+#ifdef RT_PACKED_SLAB
+                    slab2_fast_pk(pk, a, b, c, ls, ld, rs, rdist);
+#else
                     ls = slab_test_fast(org, inv, a.x, a.y, a.z, a.w, b.x, b.y, ld);
                     rs = slab_test_fast(org, inv, b.z, b.w, c.x, c.y, c.z, c.w, rdist);
+#endif
                 }
                 const float bound = BOUNDED ? tfar : h.t;
                 ls = ls && (ld < bound);
@@ -367,7 +423,7 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
 // Closest hit over a ray set (the batch form of BVH::intersect).  rays: 6
 // planes of `stride` floats; outputs indexed like the rays.
 template <bool EXACT>
-__global__ __launch_bounds__(RT_TBLOCK) void k_trace_closest(TraceScene sc, const float* __restrict__ rays, uint32_t stride, uint32_t n,
+__global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_trace_closest(TraceScene sc, const float* __restrict__ rays, uint32_t stride, uint32_t n,
                                                             TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
                                                             float* __restrict__ o_t, int32_t* __restrict__ o_id0,
                                                             int32_t* __restrict__ o_id1, float* __restrict__ o_u, float* __restrict__ o_v,
@@ -395,7 +451,7 @@ __global__ __launch_bounds__(RT_TBLOCK) void k_trace_closest(TraceScene sc, cons
 // wavefront tracer): entry i of `queue` names the slot whose ray is traced
 // and whose hit record is written.
 template <bool EXACT>
-__global__ __launch_bounds__(RT_TBLOCK) void k_extend(TraceScene sc, const float* __restrict__ rays, uint32_t stride,
+__global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_extend(TraceScene sc, const float* __restrict__ rays, uint32_t stride,
                                                      const uint32_t* __restrict__ queue, const uint32_t* __restrict__ d_count,
                                                      TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
                                                      float* __restrict__ o_t, int32_t* __restrict__ o_id0, int32_t* __restrict__ o_id1,
@@ -426,7 +482,7 @@ __global__ __launch_bounds__(RT_TBLOCK) void k_extend(TraceScene sc, const float
 // Any hit in front of a per-ray far bound (rays plane 6 = tmax): the shadow
 // rays the area lights send.
 template <bool EXACT>
-__global__ __launch_bounds__(RT_TBLOCK) void k_trace_occluded_bounded(TraceScene sc, const float* __restrict__ rays, const float* __restrict__ tmax,
+__global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_trace_occluded_bounded(TraceScene sc, const float* __restrict__ rays, const float* __restrict__ tmax,
                                                                      uint32_t stride, uint32_t n, TraceWork* __restrict__ work,
                                                                      uint32_t* __restrict__ deferred, int32_t* __restrict__ status) {
     __shared__ int32_t s_stack[RT_STACK_LDS * RT_TBLOCK];
@@ -446,7 +502,7 @@ __global__ __launch_bounds__(RT_TBLOCK) void k_trace_occluded_bounded(TraceScene
 }
 
 template <bool EXACT>
-__global__ __launch_bounds__(RT_TBLOCK) void k_trace_occluded(TraceScene sc, const float* __restrict__ rays, uint32_t stride, uint32_t n,
+__global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_trace_occluded(TraceScene sc, const float* __restrict__ rays, uint32_t stride, uint32_t n,
                                                              TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
                                                              int32_t* __restrict__ status) {
     __shared__ int32_t s_stack[RT_STACK_LDS * RT_TBLOCK];
