@@ -309,29 +309,27 @@ int run_pass(rt_ctx* c, uint32_t nb) {
     hipLaunchKernelGGL(k_generate, dim3(gslots), dim3(RT_BLOCK), 0, c->stream, c->pb, c->cam, live);
     const uint32_t gtrace = grid_for(c, nb * c->n_valid);
     const uint32_t gshade = std::min<uint32_t>(gslots, (uint32_t)c->num_cu * 8u);
-    // Two chains share the GPU: the main stream runs extend(d) -> shade(d),
-    // stream_b runs shadow(d) -> accumulate(d).  shadow(d) only needs what
-    // shade(d) wrote (queue, contributions and vertex positions of parity d&1),
-    // so it overlaps extend(d+1)/shade(d+1): the long serial tail of one
-    // persistent traversal launch is covered by the bulk of the other.
+    // Primary rays, then per bounce: shade(d) -> ONE traversal launch carrying
+    // the shadow rays of bounce d and the closest-hit rays of bounce d+1 (both
+    // are ready once shade(d) has run) -> accumulate(d) on stream_b, beside
+    // shade(d+1).  One persistent launch per bounce means one drain per bounce.
+    TraceWork* work = c->d_pass_work;
+    hipLaunchKernelGGL(k_extend<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.rays, n, c->d_q0, c->d_counts, work + D,
+                       c->d_pass_deferred, c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v, c->d_raystats);
+    hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.rays, n, c->d_q0, c->d_counts,
+                       work + D, c->d_pass_deferred, c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v, c->d_raystats);
+    if (c->n_textures && c->n_local_tiles)
+        hipLaunchKernelGGL(k_quad_duv, dim3(nb * c->n_local_tiles), dim3(RT_BLOCK), 0, c->stream, c->pb, c->d_tri_attr, c->d_duv, c->tile,
+                           (float)c->params.width, (float)c->params.height);
     const uint32_t* qin = c->d_q0;
     for (int d = 0; d < D; ++d) {
         const int p = d & 1;
         uint32_t* cnt_in = c->d_counts + d;
         uint32_t* cnt_out = c->d_counts + d + 1;
         uint32_t* qout = c->d_q[(d + 1) % 3];
-        TraceWork* work = c->d_pass_work;
         PathBuffers pbd = c->pb;
         pbd.vpos = c->vpos[p];
-        hipLaunchKernelGGL(k_extend<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.rays, n, qin, cnt_in, work + d,
-                           c->d_pass_deferred, c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v, c->d_raystats);
-        hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.rays, n, qin, cnt_in,
-                           work + d, c->d_pass_deferred, c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v,
-                           c->d_raystats);
-        if (d == 0 && c->n_textures && c->n_local_tiles)
-            hipLaunchKernelGGL(k_quad_duv, dim3(nb * c->n_local_tiles), dim3(RT_BLOCK), 0, c->stream, c->pb, c->d_tri_attr, c->d_duv, c->tile,
-                               (float)c->params.width, (float)c->params.height);
-        // shade(d) overwrites the parity-p buffers that shadow/accumulate(d-2) read
+        // shade(d) overwrites the parity-p shadow entries and the queue buffer that accumulate(d-2) reads
         if (L > 0 && d >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_acc[d - 2], 0));
         if (c->any_glossy)
             hipLaunchKernelGGL(k_shade<true>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
@@ -339,21 +337,28 @@ int run_pass(rt_ctx* c, uint32_t nb) {
         else
             hipLaunchKernelGGL(k_shade<false>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
                                qout, cnt_out, c->sq[p], c->d_raystats + 1);
-        if (L > 0) {
-            HIP_TRY(c, hipEventRecord(c->ev_shade[d], c->stream));
-            HIP_TRY(c, hipStreamWaitEvent(c->stream_b, c->ev_shade[d], 0));
-            TraceWork* w = work + D + d;
+        TraceWork* w = work + d;
+        if (d + 1 < D) {
+            hipLaunchKernelGGL(k_bounce<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq[p], L, qin, cnt_in, qout, cnt_out,
+                               w, c->d_pass_deferred_b, c->d_raystats);
+            hipLaunchKernelGGL(k_bounce<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq[p], L, qin, cnt_in, qout,
+                               cnt_out, w, c->d_pass_deferred_b, c->d_raystats);
+        } else if (L > 0) {
             if (c->any_area) {   // shadow rays towards area lights stop at the light
-                hipLaunchKernelGGL((k_shadow<false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], L, qin, cnt_in, w,
+                hipLaunchKernelGGL((k_shadow<false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq[p], L, qin, cnt_in, w,
                                    c->d_pass_deferred_b, c->d_raystats + 1);
-                hipLaunchKernelGGL((k_shadow<true, true>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], L, qin, cnt_in,
+                hipLaunchKernelGGL((k_shadow<true, true>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq[p], L, qin, cnt_in,
                                    w, c->d_pass_deferred_b, c->d_raystats + 1);
             } else {
-                hipLaunchKernelGGL((k_shadow<false, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], L, qin, cnt_in, w,
+                hipLaunchKernelGGL((k_shadow<false, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq[p], L, qin, cnt_in, w,
                                    c->d_pass_deferred_b, c->d_raystats + 1);
-                hipLaunchKernelGGL((k_shadow<true, false>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream_b, c->ts, pbd, c->sq[p], L, qin, cnt_in,
+                hipLaunchKernelGGL((k_shadow<true, false>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq[p], L, qin, cnt_in,
                                    w, c->d_pass_deferred_b, c->d_raystats + 1);
             }
+        }
+        if (L > 0) {
+            HIP_TRY(c, hipEventRecord(c->ev_shade[d], c->stream));   // the bounce's shadow rays are resolved
+            HIP_TRY(c, hipStreamWaitEvent(c->stream_b, c->ev_shade[d], 0));
             hipLaunchKernelGGL(k_accumulate, dim3(gshade), dim3(RT_BLOCK), 0, c->stream_b, pbd, c->sq[p], L, qin, cnt_in);
             HIP_TRY(c, hipEventRecord(c->ev_acc[d], c->stream_b));
         }
@@ -784,8 +789,8 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
             if ((r = dev_alloc(c, &q.contrib, 6 * cap))) return r;
             if ((r = dev_alloc(c, &q.state, cap))) return r;
         }
-        // the exact follow-up launch of k_shadow can defer up to every entry
-        if ((r = dev_alloc(c, &c->d_pass_deferred_b, cap))) return r;
+        // the exact follow-up launch of a bounce can defer up to every shadow entry and every path
+        if ((r = dev_alloc(c, &c->d_pass_deferred_b, cap + n))) return r;
     }
     if ((r = dev_alloc(c, &c->d_work, 1))) return r;
     if ((r = dev_alloc(c, &c->d_raystats, 4))) return r;

@@ -1063,6 +1063,64 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_shadow(TraceScene ts,
     }
 }
 
+// One traversal launch per bounce: the closest-hit rays of the next bounce
+// (path queue `next_queue`, written by k_shade) and the shadow rays of this
+// bounce (work items (light, entry of `queue`)) are both ready once k_shade
+// has run, so they share one persistent launch: item j < n_next is a
+// closest-hit ray, the others are shadow rays.
+template <bool EXACT>
+__global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_bounce(TraceScene ts, PathBuffers pb, ShadowQueue q, int n_lights,
+                                                                 const uint32_t* __restrict__ queue, const uint32_t* __restrict__ d_count,
+                                                                 const uint32_t* __restrict__ next_queue,
+                                                                 const uint32_t* __restrict__ d_next_count, TraceWork* __restrict__ work,
+                                                                 uint32_t* __restrict__ deferred,
+                                                                 unsigned long long* __restrict__ ray_counter) {
+    __shared__ int32_t s_stack[RT_STACK_LDS * RT_TBLOCK];
+    __shared__ __attribute__((aligned(16))) char s_top[RT_TOP_BYTES];
+    const TopTree top = stage_top_tree(ts.nodes, ts.n_nodes, s_top);
+    const uint32_t paths = *d_count, n_next = *d_next_count;
+    const uint32_t count = EXACT ? work->n_deferred : n_next + paths * (uint32_t)n_lights;
+    const size_t n = pb.n, cap = q.cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (!EXACT) atomicAdd(ray_counter, (unsigned long long)n_next);   // closest-hit rays; k_shade counted the shadow rays
+        else atomicAdd(ray_counter + 2, (unsigned long long)count);
+    }
+    auto entry = [&](uint32_t j, uint32_t& s) -> size_t {
+        const uint32_t k = j - n_next;
+        const uint32_t l = k / paths;
+        s = queue[k - l * paths];
+        return (size_t)l * n + s;
+    };
+    trace_persistent<false, EXACT, false, true>(
+        ts, count, work, deferred, s_stack, top,
+        [&](uint32_t j, f3& org, f3& dir, float& tfar, bool& any) -> bool {
+            if (j < n_next) {
+                const uint32_t s = next_queue[j];
+                any = false;
+                org = mk3(pb.rays[s], pb.rays[n + s], pb.rays[2 * n + s]);
+                dir = mk3(pb.rays[3 * n + s], pb.rays[4 * n + s], pb.rays[5 * n + s]);
+                return true;
+            }
+            uint32_t s;
+            const size_t e = entry(j, s);
+            any = true;
+            if (q.state[e] != 1) return false;
+            org = mk3(pb.vpos[s], pb.vpos[n + s], pb.vpos[2 * n + s]);
+            dir = mk3(q.dir[e], q.dir[cap + e], q.dir[2 * cap + e]);
+            tfar = q.tmax ? q.tmax[e] : __builtin_inff();
+            return true;
+        },
+        [&](uint32_t j, const HitRec& h) {
+            if (j < n_next) {
+                const uint32_t s = next_queue[j];
+                pb.hit_t[s] = h.t; pb.hit_id0[s] = h.id0; pb.hit_id1[s] = h.id1; pb.hit_u[s] = h.u; pb.hit_v[s] = h.v;
+            } else {
+                uint32_t s;
+                if (h.id1 < 0) q.state[entry(j, s)] = 2;
+            }
+        });
+}
+
 // The adds of src/cpu/PathTracer.cpp:107/:109 and :123 for every path of the
 // bounce, light by light in the reference's loop order.
 __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(PathBuffers pb, ShadowQueue q, int n_lights, const uint32_t* __restrict__ queue,

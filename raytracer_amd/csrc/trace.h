@@ -249,7 +249,10 @@ struct TraceWork {
 // occluded by hits in front of it, and the bound takes the place of the
 // never-shrinking hit.dist of the reference's loop (src/scene/BVH.cpp:70,106-107).
 // A bound of +inf is the reference's unbounded shadow ray.
-template <bool ANY_HIT, bool EXACT, bool BOUNDED = false, typename Load, typename Done>
+//
+// MIXED: closest-hit and any-hit rays in one launch; `load` says per item which
+// it is (and gives any-hit rays their far bound, +inf if none).
+template <bool ANY_HIT, bool EXACT, bool BOUNDED = false, bool MIXED = false, typename Load, typename Done>
 RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* work, uint32_t* deferred, int32_t* lds_stack,
                              const TopTree& top, Load load, Done done) {
     const uint32_t tid = threadIdx.x;
@@ -283,6 +286,8 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
     h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
     float tfar = inf;
     static_assert(!BOUNDED || ANY_HIT, "a far bound only makes sense for any-hit rays");
+    static_assert(!MIXED || (!ANY_HIT && !BOUNDED), "MIXED takes the ray kind per item");
+    bool any_lane = ANY_HIT;
 
     for (;;) {
         const unsigned long long m_idle = __ballot(!have);
@@ -308,7 +313,8 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     if (EXACT) i = deferred[i];
                     item = i;
                     bool present;
-                    if constexpr (BOUNDED) present = load(i, org, dir, tfar);
+                    if constexpr (MIXED) present = load(i, org, dir, tfar, any_lane);
+                    else if constexpr (BOUNDED) present = load(i, org, dir, tfar);
                     else present = load(i, org, dir);
                     inv = make_invdir(dir);
 #ifdef RT_PACKED_SLAB
@@ -352,8 +358,12 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     left = l2.x; right = l2.y;
                     // pins these as LDS reads: without it the compiler folds the two
                     // branches into flat-address loads of a selected pointer
+#ifdef RT_PIN_MIN
+                    asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(left));
+#else
                     asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c.x), "+v"(c.y),
                                  "+v"(c.z), "+v"(c.w), "+v"(left), "+v"(right));
+#endif
                 } else {
                     const float4* np = sc.nodes + (size_t)cur * 4;
                     a = np[0]; b = np[1]; c = np[2];
@@ -373,7 +383,7 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     rs = slab_test_fast(org, inv, b.z, b.w, c.x, c.y, c.z, c.w, rdist);
 #endif
                 }
-                const float bound = BOUNDED ? tfar : h.t;
+                const float bound = MIXED ? (any_lane ? tfar : h.t) : (BOUNDED ? tfar : h.t);
                 ls = ls && (ld < bound);
                 rs = rs && (rdist < bound);
                 if (ls && rs) {
@@ -400,12 +410,13 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                 bool finished = false;
                 if (tri_test(org, dir, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v)) {
                     // src/scene/BVH.cpp:139 (closest) / :93 (any)
-                    const bool in_range = ANY_HIT ? (!BOUNDED || !(tfar < inf) || t < tfar) : (t < h.t);
+                    const bool any_ray = MIXED ? any_lane : ANY_HIT;
+                    const bool in_range = any_ray ? (!(BOUNDED || MIXED) || !(tfar < inf) || t < tfar) : (t < h.t);
                     if (t > 0.0001f && in_range) {
                         h.t = t; h.u = u; h.v = v;
                         h.id1 = __float_as_int(c.y);
                         h.id0 = __float_as_int(c.z);
-                        if (ANY_HIT) finished = true;
+                        if (any_ray) finished = true;
                     }
                 }
                 if (!finished && sp > 0) {
