@@ -28,11 +28,15 @@
 
 class HipPathTracer {
    public:
-    HipPathTracer(const rt_scene_desc& scene, int width, int height, int max_depth = 4, uint64_t seed = 0, int device = 0)
-        : _width(width), _height(height) {
+    // passes_per_update = 1 is the reference's protocol (one 1-spp pass per update(), src/cpu/Integrator.cpp:26-67);
+    // a larger value makes every update() add that many passes, traced together as one wavefront.
+    HipPathTracer(const rt_scene_desc& scene, int width, int height, int max_depth = 4, uint64_t seed = 0, int device = 0,
+                  uint32_t passes_per_update = 1)
+        : _width(width), _height(height), _passes(passes_per_update ? passes_per_update : 1) {
         rt_params p{};
         p.width = width; p.height = height; p.max_depth = max_depth; p.tile_size = 64;
         p.seed = seed; p.device = device; p.rank = 0; p.world = 1;
+        p.batch = _passes;   // path state sized for what one update() traces
         if (rt_create(&scene, &p, &_ctx) != RT_OK) throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
         _frame.assign((size_t)width * height * 4, 0.f);
     }
@@ -81,17 +85,18 @@ class HipPathTracer {
    protected:
     // src/cpu/Integrator.cpp:26-67 with the tile pool replaced by one rt_render pass
     void update() {
-        if (rt_set_camera(_ctx, _pos, _right, _up, _forward) != RT_OK || rt_render(_ctx, 1) != RT_OK ||
+        if (rt_set_camera(_ctx, _pos, _right, _up, _forward) != RT_OK || rt_render(_ctx, _passes) != RT_OK ||
             rt_read_film(_ctx, _frame.data()) != RT_OK) {
             _error = rt_last_error(_ctx);
             _isRun = false;
             return;
         }
-        _frames++;
+        _frames += _passes;
     }
 
     rt_ctx* _ctx = nullptr;
     int _width, _height;
+    uint32_t _passes = 1;
     float _pos[3]{}, _right[3]{}, _forward[3]{}, _up[3]{};
     std::vector<float> _frame;
     uint64_t _frames = 0;

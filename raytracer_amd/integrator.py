@@ -15,8 +15,11 @@ from .scenes import Camera, Scene
 class HipPathTracer:
     tileSize = 64  # src/cpu/Integrator.hpp:56
 
-    def __init__(self, scene: Scene, width: int, height: int, max_depth: int = 4, seed: int = 0, device: int = 0):
-        self._ctx = Context(scene, width, height, max_depth=max_depth, seed=seed, device=device)
+    def __init__(self, scene: Scene, width: int, height: int, max_depth: int = 4, seed: int = 0, device: int = 0,
+                 passes_per_update: int = 1):
+        # one pass per update() is the reference's protocol; more passes per update are traced as one wavefront
+        self._passes = max(1, int(passes_per_update))
+        self._ctx = Context(scene, width, height, max_depth=max_depth, seed=seed, device=device, batch=self._passes)
         self._width, self._height = width, height
         self._frame = np.zeros((height, width, 4), np.float32)
         self._texture = np.zeros((height, width, 4), np.float32)
@@ -72,9 +75,9 @@ class HipPathTracer:
     # src/cpu/Integrator.cpp:26-67
     def update(self):
         self._ctx.set_camera(self._camera)
-        self._ctx.render(1)
+        self._ctx.render(self._passes)
         self._frame = self._ctx.read_film()
-        self._frames += 1
+        self._frames += self._passes
 
     @property
     def frames(self) -> int:
