@@ -33,9 +33,7 @@ struct rt_ctx {
     int device = 0;
     int num_cu = 256;
     hipStream_t stream = nullptr;          // main stream: extend / shade chain, rt_trace_*
-    hipStream_t stream_b = nullptr;        // shadow / accumulate chain of a pass
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    std::vector<hipEvent_t> ev_shade, ev_acc;  // per bounce: shade(d) done on the main stream / accumulate(d) done on stream_b
     std::string err;
 
     rt_params params{};
@@ -76,13 +74,12 @@ struct rt_ctx {
     std::vector<void*> allocs;
     PathBuffers pb{};
     uint32_t* d_q0 = nullptr;
-    uint32_t* d_q[3] = {nullptr, nullptr, nullptr};  // path queues, rotating: bounce d+1 is written while accumulate(d) still reads bounce d
+    uint32_t* d_q[2] = {nullptr, nullptr};  // path queues of odd / even bounces (bounce 0 reads d_q0)
     // [D+1] queue counts, then [D] shadow-queue counts
     uint32_t* d_counts = nullptr;
     uint32_t* d_counts_init = nullptr;  // template copied in at the start of a pass
     uint32_t n_counts = 0;
-    ShadowQueue sq[2]{};                   // by bounce parity
-    float* vpos[2] = {nullptr, nullptr};   // shaded-vertex positions, by bounce parity
+    ShadowQueue sq{};                      // shadow entries of the bounce being resolved
     uint32_t* d_pass_deferred_b = nullptr; // deferred list of the shadow launches
     unsigned long long* d_raystats = nullptr;  // [0] closest, [1] shadow, [2] / [3] of those, rays re-traced by the exact follow-up launches
     TraceWork* d_work = nullptr;               // work counters of the rt_trace_* launches
@@ -311,8 +308,9 @@ int run_pass(rt_ctx* c, uint32_t nb) {
     const uint32_t gshade = std::min<uint32_t>(gslots, (uint32_t)c->num_cu * 8u);
     // Primary rays, then per bounce: shade(d) -> ONE traversal launch carrying
     // the shadow rays of bounce d and the closest-hit rays of bounce d+1 (both
-    // are ready once shade(d) has run) -> accumulate(d) on stream_b, beside
-    // shade(d+1).  One persistent launch per bounce means one drain per bounce.
+    // are ready once shade(d) has run) -> accumulate(d).  One persistent launch
+    // per bounce means one drain per bounce; everything is ordered on one stream
+    // (k_accumulate beside k_shade on a second stream measured 2 % slower).
     TraceWork* work = c->d_pass_work;
     hipLaunchKernelGGL(k_extend<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.rays, n, c->d_q0, c->d_counts, work + D,
                        c->d_pass_deferred, c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v, c->d_raystats);
@@ -323,48 +321,40 @@ int run_pass(rt_ctx* c, uint32_t nb) {
                            (float)c->params.width, (float)c->params.height);
     const uint32_t* qin = c->d_q0;
     for (int d = 0; d < D; ++d) {
-        const int p = d & 1;
         uint32_t* cnt_in = c->d_counts + d;
         uint32_t* cnt_out = c->d_counts + d + 1;
-        uint32_t* qout = c->d_q[(d + 1) % 3];
-        PathBuffers pbd = c->pb;
-        pbd.vpos = c->vpos[p];
-        // shade(d) overwrites the parity-p shadow entries and the queue buffer that accumulate(d-2) reads
-        if (L > 0 && d >= 2) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_acc[d - 2], 0));
+        uint32_t* qout = c->d_q[(d + 1) & 1];
+        const PathBuffers& pbd = c->pb;
         if (c->any_glossy)
             hipLaunchKernelGGL(k_shade<true>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
-                               qout, cnt_out, c->sq[p], c->d_raystats + 1);
+                               qout, cnt_out, c->sq, c->d_raystats + 1);
         else
             hipLaunchKernelGGL(k_shade<false>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
-                               qout, cnt_out, c->sq[p], c->d_raystats + 1);
+                               qout, cnt_out, c->sq, c->d_raystats + 1);
         TraceWork* w = work + d;
         if (d + 1 < D) {
-            hipLaunchKernelGGL(k_bounce<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq[p], L, qin, cnt_in, qout, cnt_out,
+            hipLaunchKernelGGL(k_bounce<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, qout, cnt_out,
                                w, c->d_pass_deferred_b, c->d_raystats);
-            hipLaunchKernelGGL(k_bounce<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq[p], L, qin, cnt_in, qout,
+            hipLaunchKernelGGL(k_bounce<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, qout,
                                cnt_out, w, c->d_pass_deferred_b, c->d_raystats);
         } else if (L > 0) {
             if (c->any_area) {   // shadow rays towards area lights stop at the light
-                hipLaunchKernelGGL((k_shadow<false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq[p], L, qin, cnt_in, w,
+                hipLaunchKernelGGL((k_shadow<false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, w,
                                    c->d_pass_deferred_b, c->d_raystats + 1);
-                hipLaunchKernelGGL((k_shadow<true, true>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq[p], L, qin, cnt_in,
+                hipLaunchKernelGGL((k_shadow<true, true>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in,
                                    w, c->d_pass_deferred_b, c->d_raystats + 1);
             } else {
-                hipLaunchKernelGGL((k_shadow<false, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq[p], L, qin, cnt_in, w,
+                hipLaunchKernelGGL((k_shadow<false, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, w,
                                    c->d_pass_deferred_b, c->d_raystats + 1);
-                hipLaunchKernelGGL((k_shadow<true, false>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq[p], L, qin, cnt_in,
+                hipLaunchKernelGGL((k_shadow<true, false>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in,
                                    w, c->d_pass_deferred_b, c->d_raystats + 1);
             }
         }
         if (L > 0) {
-            HIP_TRY(c, hipEventRecord(c->ev_shade[d], c->stream));   // the bounce's shadow rays are resolved
-            HIP_TRY(c, hipStreamWaitEvent(c->stream_b, c->ev_shade[d], 0));
-            hipLaunchKernelGGL(k_accumulate, dim3(gshade), dim3(RT_BLOCK), 0, c->stream_b, pbd, c->sq[p], L, qin, cnt_in);
-            HIP_TRY(c, hipEventRecord(c->ev_acc[d], c->stream_b));
+            hipLaunchKernelGGL(k_accumulate, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->sq, L, qin, cnt_in);
         }
         qin = qout;
     }
-    if (L > 0) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_acc[D - 1], 0));
     hipLaunchKernelGGL(k_film, dim3((c->n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->pb, (float)c->frames, nb);
     HIP_TRY(c, hipGetLastError());
     c->frames += nb;
@@ -383,12 +373,8 @@ void rt_destroy(rt_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
     for (void* p : c->allocs) (void)hipFree(p);
     c->dbvh.release();
-    for (hipEvent_t e : c->ev_shade) (void)hipEventDestroy(e);
-    for (hipEvent_t e : c->ev_acc) (void)hipEventDestroy(e);
-    if (c->stream_b) (void)hipStreamDestroy(c->stream_b);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -475,14 +461,6 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->stream_b, hipStreamNonBlocking));
-    for (int d = 0; d < pr->max_depth; ++d) {
-        hipEvent_t e1 = nullptr, e2 = nullptr;
-        HIP_TRY(c, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-        c->ev_shade.push_back(e1);
-        HIP_TRY(c, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-        c->ev_acc.push_back(e2);
-    }
     HIP_TRY(c, hipEventCreate(&c->ev0));
     HIP_TRY(c, hipEventCreate(&c->ev1));
 
@@ -717,7 +695,7 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     // path-state budget of 48 GiB and 32-bit entry indices
     {
         const uint64_t L1 = (uint64_t)std::max<uint32_t>(1, sd->n_lights);
-        const uint64_t per_slot = 160 + 82 * L1;   // bytes of path state and shadow entries per slot
+        const uint64_t per_slot = 140 + 45 * L1;   // bytes of path state and shadow entries per slot
         uint64_t S = pr->batch ? pr->batch : 8;
         const uint64_t one = std::max<uint64_t>(1, (uint64_t)c->n_slots);
         S = std::min<uint64_t>(S, std::max<uint64_t>(1, (48ull << 30) / (per_slot * one)));
@@ -739,7 +717,6 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     }
     if ((r = dev_alloc(c, &c->d_q[0], n))) return r;
     if ((r = dev_alloc(c, &c->d_q[1], n))) return r;
-    if ((r = dev_alloc(c, &c->d_q[2], n))) return r;
     if ((r = dev_alloc(c, &c->pb.rays, 6 * n))) return r;
     if ((r = dev_alloc(c, &c->pb.hit_t, n))) return r;
     if ((r = dev_alloc(c, &c->pb.hit_id0, n))) return r;
@@ -748,9 +725,7 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     if ((r = dev_alloc(c, &c->pb.hit_v, n))) return r;
     if ((r = dev_alloc(c, &c->pb.beta, 3 * n))) return r;
     if ((r = dev_alloc(c, &c->pb.L, 3 * n))) return r;
-    if ((r = dev_alloc(c, &c->vpos[0], 3 * n))) return r;
-    if ((r = dev_alloc(c, &c->vpos[1], 3 * n))) return r;
-    c->pb.vpos = c->vpos[0];
+    if ((r = dev_alloc(c, &c->pb.vpos, 3 * n))) return r;
     if ((r = dev_alloc(c, &c->pb.status, n))) return r;
     if ((r = dev_alloc(c, &c->pb.film, (size_t)c->n_slots))) return r;
     HIP_TRY(c, hipMemset(c->pb.film, 0, (c->n_slots ? c->n_slots : 1) * sizeof(float4)));
@@ -781,7 +756,7 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
             return RT_ERR_LIMIT;
         }
         for (int p = 0; p < 2; ++p) {
-            ShadowQueue& q = c->sq[p];
+            ShadowQueue& q = c->sq;
             q.cap = (uint32_t)cap;
             if ((r = dev_alloc(c, &q.dir, 3 * cap))) return r;
             q.tmax = nullptr;
@@ -906,7 +881,7 @@ int rt_read_last_bounce_rays(rt_ctx* c, float* rays_soa, uint32_t cap, uint32_t*
     if (!cap || !count) return RT_OK;
     const uint32_t take = std::min(count, cap);
     std::vector<uint32_t> q(take);
-    HIP_TRY(c, hipMemcpy(q.data(), c->d_q[(D - 1) % 3], (size_t)take * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(q.data(), c->d_q[(D - 1) & 1], (size_t)take * sizeof(uint32_t), hipMemcpyDeviceToHost));
     const size_t n = c->n_total;
     std::vector<float> rays(6 * n);
     HIP_TRY(c, hipMemcpy(rays.data(), c->pb.rays, rays.size() * sizeof(float), hipMemcpyDeviceToHost));
