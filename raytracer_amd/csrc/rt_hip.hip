@@ -74,7 +74,11 @@ struct rt_ctx {
     std::vector<void*> allocs;
     PathBuffers pb{};
     uint32_t* d_q0 = nullptr;
-    uint32_t* d_q[2] = {nullptr, nullptr};  // path queues of odd / even bounces (bounce 0 reads d_q0)
+    // path state of the current / next bounce (rays, beta, slot ids), swapped after every bounce
+    float* d_rays[2] = {nullptr, nullptr};
+    float* d_beta[2] = {nullptr, nullptr};
+    uint32_t* d_slot[2] = {nullptr, nullptr};
+    int last_buf = 0;   // which of the two holds the rays of the deepest bounce of the last batch
     // [D+1] queue counts, then [D] shadow-queue counts
     uint32_t* d_counts = nullptr;
     uint32_t* d_counts_init = nullptr;  // template copied in at the start of a pass
@@ -303,6 +307,8 @@ int run_pass(rt_ctx* c, uint32_t nb) {
     HIP_TRY(c, hipMemsetAsync(c->d_pass_work, 0, c->n_pass_work * sizeof(TraceWork), c->stream));
     const uint32_t live = nb * c->n_slots;
     const uint32_t gslots = (live + RT_BLOCK - 1) / RT_BLOCK;
+    c->pb.rays = c->d_rays[0]; c->pb.beta = c->d_beta[0]; c->pb.slot = c->d_slot[0];
+    c->pb.rays_next = c->d_rays[1]; c->pb.beta_next = c->d_beta[1]; c->pb.slot_next = c->d_slot[1];
     hipLaunchKernelGGL(k_generate, dim3(gslots), dim3(RT_BLOCK), 0, c->stream, c->pb, c->cam, live);
     const uint32_t gtrace = grid_for(c, nb * c->n_valid);
     const uint32_t gshade = std::min<uint32_t>(gslots, (uint32_t)c->num_cu * 8u);
@@ -319,24 +325,29 @@ int run_pass(rt_ctx* c, uint32_t nb) {
     if (c->n_textures && c->n_local_tiles)
         hipLaunchKernelGGL(k_quad_duv, dim3(nb * c->n_local_tiles), dim3(RT_BLOCK), 0, c->stream, c->pb, c->d_tri_attr, c->d_duv, c->tile,
                            (float)c->params.width, (float)c->params.height);
+    // Bounce 0 walks the slots inside the film (d_q0) with path index = slot;
+    // from bounce 1 on the paths are the first counts[d] entries of the
+    // current arrays (queue == nullptr).
     const uint32_t* qin = c->d_q0;
+    int cur = 0;
     for (int d = 0; d < D; ++d) {
         uint32_t* cnt_in = c->d_counts + d;
         uint32_t* cnt_out = c->d_counts + d + 1;
-        uint32_t* qout = c->d_q[(d + 1) & 1];
-        const PathBuffers& pbd = c->pb;
+        PathBuffers pbd = c->pb;
+        pbd.rays = c->d_rays[cur]; pbd.beta = c->d_beta[cur]; pbd.slot = c->d_slot[cur];
+        pbd.rays_next = c->d_rays[cur ^ 1]; pbd.beta_next = c->d_beta[cur ^ 1]; pbd.slot_next = c->d_slot[cur ^ 1];
         if (c->any_glossy)
             hipLaunchKernelGGL(k_shade<true>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
-                               qout, cnt_out, c->sq, c->d_raystats + 1);
+                               cnt_out, c->sq, c->d_raystats + 1);
         else
             hipLaunchKernelGGL(k_shade<false>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
-                               qout, cnt_out, c->sq, c->d_raystats + 1);
+                               cnt_out, c->sq, c->d_raystats + 1);
         TraceWork* w = work + d;
         if (d + 1 < D) {
-            hipLaunchKernelGGL(k_bounce<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, qout, cnt_out,
+            hipLaunchKernelGGL(k_bounce<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, cnt_out, w,
+                               c->d_pass_deferred_b, c->d_raystats);
+            hipLaunchKernelGGL(k_bounce<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, cnt_out,
                                w, c->d_pass_deferred_b, c->d_raystats);
-            hipLaunchKernelGGL(k_bounce<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, qout,
-                               cnt_out, w, c->d_pass_deferred_b, c->d_raystats);
         } else if (L > 0) {
             if (c->any_area) {   // shadow rays towards area lights stop at the light
                 hipLaunchKernelGGL((k_shadow<false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, w,
@@ -350,11 +361,13 @@ int run_pass(rt_ctx* c, uint32_t nb) {
                                    w, c->d_pass_deferred_b, c->d_raystats + 1);
             }
         }
-        if (L > 0) {
-            hipLaunchKernelGGL(k_accumulate, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->sq, L, qin, cnt_in);
+        if (L > 0) hipLaunchKernelGGL(k_accumulate, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->sq, L, qin, cnt_in);
+        if (d + 1 < D) {
+            qin = nullptr;
+            cur ^= 1;
         }
-        qin = qout;
     }
+    c->last_buf = cur;
     hipLaunchKernelGGL(k_film, dim3((c->n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->pb, (float)c->frames, nb);
     HIP_TRY(c, hipGetLastError());
     c->frames += nb;
@@ -695,7 +708,7 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     // path-state budget of 48 GiB and 32-bit entry indices
     {
         const uint64_t L1 = (uint64_t)std::max<uint32_t>(1, sd->n_lights);
-        const uint64_t per_slot = 140 + 45 * L1;   // bytes of path state and shadow entries per slot
+        const uint64_t per_slot = 170 + 45 * L1;   // bytes of path state and shadow entries per slot
         uint64_t S = pr->batch ? pr->batch : 8;
         const uint64_t one = std::max<uint64_t>(1, (uint64_t)c->n_slots);
         S = std::min<uint64_t>(S, std::max<uint64_t>(1, (48ull << 30) / (per_slot * one)));
@@ -715,15 +728,17 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         if ((r = dev_upload(c, &c->d_slot_pixel, sp.data(), n))) return r;
         if ((r = dev_upload(c, &c->d_q0, qa.data(), qa.size()))) return r;
     }
-    if ((r = dev_alloc(c, &c->d_q[0], n))) return r;
-    if ((r = dev_alloc(c, &c->d_q[1], n))) return r;
-    if ((r = dev_alloc(c, &c->pb.rays, 6 * n))) return r;
+    for (int k = 0; k < 2; ++k) {
+        if ((r = dev_alloc(c, &c->d_rays[k], 6 * n))) return r;
+        if ((r = dev_alloc(c, &c->d_beta[k], 3 * n))) return r;
+        if ((r = dev_alloc(c, &c->d_slot[k], n))) return r;
+    }
+    c->pb.rays = c->d_rays[0];
     if ((r = dev_alloc(c, &c->pb.hit_t, n))) return r;
     if ((r = dev_alloc(c, &c->pb.hit_id0, n))) return r;
     if ((r = dev_alloc(c, &c->pb.hit_id1, n))) return r;
     if ((r = dev_alloc(c, &c->pb.hit_u, n))) return r;
     if ((r = dev_alloc(c, &c->pb.hit_v, n))) return r;
-    if ((r = dev_alloc(c, &c->pb.beta, 3 * n))) return r;
     if ((r = dev_alloc(c, &c->pb.L, 3 * n))) return r;
     if ((r = dev_alloc(c, &c->pb.vpos, 3 * n))) return r;
     if ((r = dev_alloc(c, &c->pb.status, n))) return r;
@@ -880,15 +895,20 @@ int rt_read_last_bounce_rays(rt_ctx* c, float* rays_soa, uint32_t cap, uint32_t*
     *n_out = count;
     if (!cap || !count) return RT_OK;
     const uint32_t take = std::min(count, cap);
-    std::vector<uint32_t> q(take);
-    HIP_TRY(c, hipMemcpy(q.data(), c->d_q[(D - 1) & 1], (size_t)take * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // the paths of the deepest bounce are the first `count` entries of the arrays that were current then
     const size_t n = c->n_total;
-    std::vector<float> rays(6 * n);
-    HIP_TRY(c, hipMemcpy(rays.data(), c->pb.rays, rays.size() * sizeof(float), hipMemcpyDeviceToHost));
-    // the queue is filled in whatever order workgroups finish: hand the rays out in slot order
-    std::sort(q.begin(), q.end());
+    std::vector<uint32_t> slot(count);
+    std::vector<float> rays((size_t)6 * count);
+    HIP_TRY(c, hipMemcpy(slot.data(), c->d_slot[c->last_buf], (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 6; ++k)
+        HIP_TRY(c, hipMemcpy(&rays[(size_t)k * count], c->d_rays[c->last_buf] + (size_t)k * n, (size_t)count * sizeof(float),
+                             hipMemcpyDeviceToHost));
+    // they were appended in whatever order workgroups finished: hand them out in slot order
+    std::vector<uint32_t> order(count);
+    for (uint32_t i = 0; i < count; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return slot[a] < slot[b]; });
     for (uint32_t i = 0; i < take; ++i)
-        for (int k = 0; k < 6; ++k) rays_soa[(size_t)k * cap + i] = rays[(size_t)k * n + q[i]];
+        for (int k = 0; k < 6; ++k) rays_soa[(size_t)k * cap + i] = rays[(size_t)k * count + order[i]];
     return RT_OK;
 }
 

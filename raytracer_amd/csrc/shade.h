@@ -38,15 +38,24 @@ struct DevLight {
 };
 
 struct PathBuffers {
+    // State of the paths of the current bounce, indexed by PATH INDEX: at bounce
+    // 0 the path index is the slot; from bounce 1 on, k_shade writes the
+    // surviving paths to consecutive indices of the *_next arrays, so every
+    // bounce reads and writes dense, coalesced planes however few paths are left.
     float* rays;        // 6 planes: ox oy oz dx dy dz
-    float* hit_t;
+    float* beta;        // 3 planes (the reference's `threshold`)
+    uint32_t* slot;     // slot of each path
+    float* rays_next;
+    float* beta_next;
+    uint32_t* slot_next;
+    float* hit_t;       // hit of each path's ray, by path index
     int32_t* hit_id0;
     int32_t* hit_id1;
     float* hit_u;
     float* hit_v;
-    float* beta;        // 3 planes (the reference's `threshold`)
+    float* vpos;        // 3 planes: position of the vertex being shaded, by path index
+    // Per slot (a film pixel of one pass of the batch)
     float* L;           // 3 planes (the reference's `pixelColor`)
-    float* vpos;        // 3 planes: position of the vertex being shaded
     uint32_t* status;   // 1 = the primary ray hit (film takes the running mean)
     const uint32_t* slot_pixel;  // y*W+x, or 0xFFFFFFFF for a slot outside the film
     float4* film;       // n1 entries: one per film pixel slot
@@ -705,6 +714,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(PathBuffers pb, CameraK c
     if (s >= count) return;
     uint32_t pix = pb.slot_pixel[s];
     pb.status[s] = 0;
+    pb.slot[s] = s;
     size_t n = pb.n;
     pb.beta[s] = 1.f; pb.beta[n + s] = 1.f; pb.beta[2 * n + s] = 1.f;
     pb.L[s] = 0.f; pb.L[n + s] = 0.f; pb.L[2 * n + s] = 0.f;
@@ -819,8 +829,8 @@ struct ShadowQueue {
 template <bool GLOSSY>
 __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene sc, int depth, int max_depth, uint64_t seed_mixed,
                                                     uint32_t first_pass, const uint32_t* __restrict__ queue,
-                                                    const uint32_t* __restrict__ d_count, uint32_t* __restrict__ next_queue,
-                                                    uint32_t* __restrict__ next_count, ShadowQueue sq,
+                                                    const uint32_t* __restrict__ d_count, uint32_t* __restrict__ next_count,
+                                                    ShadowQueue sq,
                                                     unsigned long long* __restrict__ shadow_ray_counter) {
     __shared__ uint32_t s_cnt[RT_BLOCK / 64 + 1];
     const uint32_t count = *d_count;
@@ -832,15 +842,17 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
     for (uint32_t bbase = blockIdx.x * RT_BLOCK; bbase < count; bbase += gsize) {
         uint32_t i = bbase + threadIdx.x;
         bool valid = i < count;
-        uint32_t s = valid ? queue[i] : 0u;
+        // path index: the entries of `queue` at bounce 0 (slots inside the film), the entry number afterwards
+        const uint32_t pi = valid ? (queue ? queue[i] : i) : 0u;
+        const uint32_t s = valid ? pb.slot[pi] : 0u;
         bool hit = false;
         f3 org = mk3(0.f, 0.f, 0.f), dir = mk3(0.f, 0.f, 1.f);
         int32_t id0 = -1, id1 = -1;
         if (valid) {
-            org = mk3(pb.rays[s], pb.rays[n + s], pb.rays[2 * n + s]);
-            dir = mk3(pb.rays[3 * n + s], pb.rays[4 * n + s], pb.rays[5 * n + s]);
-            id1 = pb.hit_id1[s];
-            id0 = pb.hit_id0[s];
+            org = mk3(pb.rays[pi], pb.rays[n + pi], pb.rays[2 * n + pi]);
+            dir = mk3(pb.rays[3 * n + pi], pb.rays[4 * n + pi], pb.rays[5 * n + pi]);
+            id1 = pb.hit_id1[pi];
+            id0 = pb.hit_id0[pi];
             hit = id1 >= 0;
             if (!hit && depth == 0) {
                 // src/cpu/PathTracer.cpp:61-65: the film takes the summed le, no accumulation
@@ -863,7 +875,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
         if (hit) {
             if (depth == 0) pb.status[s] = 1;
             pixel = pb.slot_pixel[s];
-            float t = pb.hit_t[s], hu = pb.hit_u[s], hv = pb.hit_v[s];
+            float t = pb.hit_t[pi], hu = pb.hit_u[pi], hv = pb.hit_v[pi];
             float bc[3] = {1.0f - hu - hv, hu, hv};
             vpos = org + dir * t;
             const float* at = sc.tri_attr + (size_t)(id1 / 3) * 36;
@@ -923,8 +935,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
                 }
             }
             out = -dir;
-            pb.vpos[s] = vpos.x; pb.vpos[n + s] = vpos.y; pb.vpos[2 * n + s] = vpos.z;
-            beta = mk3(pb.beta[s], pb.beta[n + s], pb.beta[2 * n + s]);
+            pb.vpos[pi] = vpos.x; pb.vpos[n + pi] = vpos.y; pb.vpos[2 * n + pi] = vpos.z;
+            beta = mk3(pb.beta[pi], pb.beta[n + pi], pb.beta[2 * n + pi]);
         }
 
         // ---- light loop, src/cpu/PathTracer.cpp:96-125
@@ -968,9 +980,9 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
             // or not it is occluded (L + 0 == L), so it is not traced
             emit = emit && !(is_zero3(C) && is_zero3(C2));
             n_emit += (uint32_t)__popcll(__ballot(emit));
-            if (valid) sq.state[(size_t)l * n + s] = emit ? 1 : 0;
+            if (valid) sq.state[(size_t)l * n + pi] = emit ? 1 : 0;
             if (emit) {
-                const size_t cap = sq.cap, e = (size_t)l * n + s;
+                const size_t cap = sq.cap, e = (size_t)l * n + pi;
                 sq.dir[e] = in.x; sq.dir[cap + e] = in.y; sq.dir[2 * cap + e] = in.z;
                 if (sq.tmax) sq.tmax[e] = tmax;
                 sq.contrib[e] = C.x; sq.contrib[cap + e] = C.y; sq.contrib[2 * cap + e] = C.z;
@@ -981,8 +993,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
         // ---- BSDF bounce, src/cpu/PathTracer.cpp:127-144.  The closest-hit
         // ray of the last iteration feeds nothing and is not generated.
         bool alive = false;
+        f3 nextDir = mk3(0.f, 0.f, 0.f);
         if (hit && depth + 1 < max_depth) {
-            f3 nextDir = mk3(0.f, 0.f, 0.f);
             float nextPDF = 0.0f;
             f2 u3;
             u3.x = rng_u01(seed_mixed, pixel, pass, dim_bounce(depth, L, 0));
@@ -991,13 +1003,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
             if (!(is_zero3(bsdfColor) || nextPDF == 0.0f)) {
                 alive = true;
                 beta = beta * (bsdfColor * fabsf(dot3(nextDir, vn)) / nextPDF);
-                pb.beta[s] = beta.x; pb.beta[n + s] = beta.y; pb.beta[2 * n + s] = beta.z;
-                pb.rays[s] = vpos.x; pb.rays[n + s] = vpos.y; pb.rays[2 * n + s] = vpos.z;
-                pb.rays[3 * n + s] = nextDir.x; pb.rays[4 * n + s] = nextDir.y; pb.rays[5 * n + s] = nextDir.z;
             }
         }
+        // the surviving path moves to the next free index of the next bounce's arrays
         uint32_t k = block_append(alive, next_count, s_cnt);
-        if (alive) next_queue[k] = s;
+        if (alive) {
+            pb.slot_next[k] = s;
+            pb.beta_next[k] = beta.x; pb.beta_next[n + k] = beta.y; pb.beta_next[2 * n + k] = beta.z;
+            pb.rays_next[k] = vpos.x; pb.rays_next[n + k] = vpos.y; pb.rays_next[2 * n + k] = vpos.z;
+            pb.rays_next[3 * n + k] = nextDir.x; pb.rays_next[4 * n + k] = nextDir.y; pb.rays_next[5 * n + k] = nextDir.z;
+        }
     }
     // ray statistics: one atomic per workgroup
     if ((threadIdx.x & 63u) == 0) s_cnt[threadIdx.x >> 6] = n_emit;
@@ -1026,9 +1041,11 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_shadow(TraceScene ts,
     const uint32_t count = EXACT ? work->n_deferred : paths * (uint32_t)n_lights;
     const size_t n = pb.n, cap = q.cap;
     if (EXACT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter + 2, (unsigned long long)count);
+    // work item j -> (light, path index); `queue` lists the path indices at bounce 0 and is null afterwards
     auto entry = [&](uint32_t j, uint32_t& s) -> size_t {
         const uint32_t l = j / paths;
-        s = queue[j - l * paths];
+        const uint32_t e = j - l * paths;
+        s = queue ? queue[e] : e;
         return (size_t)l * n + s;
     };
     auto mark = [&](uint32_t j, const HitRec& h) {
@@ -1071,7 +1088,6 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_shadow(TraceScene ts,
 template <bool EXACT>
 __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_bounce(TraceScene ts, PathBuffers pb, ShadowQueue q, int n_lights,
                                                                  const uint32_t* __restrict__ queue, const uint32_t* __restrict__ d_count,
-                                                                 const uint32_t* __restrict__ next_queue,
                                                                  const uint32_t* __restrict__ d_next_count, TraceWork* __restrict__ work,
                                                                  uint32_t* __restrict__ deferred,
                                                                  unsigned long long* __restrict__ ray_counter) {
@@ -1088,17 +1104,17 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_bounce(TraceScene ts,
     auto entry = [&](uint32_t j, uint32_t& s) -> size_t {
         const uint32_t k = j - n_next;
         const uint32_t l = k / paths;
-        s = queue[k - l * paths];
+        const uint32_t e = k - l * paths;
+        s = queue ? queue[e] : e;
         return (size_t)l * n + s;
     };
     trace_persistent<false, EXACT, false, true>(
         ts, count, work, deferred, s_stack, top,
         [&](uint32_t j, f3& org, f3& dir, float& tfar, bool& any) -> bool {
-            if (j < n_next) {
-                const uint32_t s = next_queue[j];
+            if (j < n_next) {   // path j of the next bounce
                 any = false;
-                org = mk3(pb.rays[s], pb.rays[n + s], pb.rays[2 * n + s]);
-                dir = mk3(pb.rays[3 * n + s], pb.rays[4 * n + s], pb.rays[5 * n + s]);
+                org = mk3(pb.rays_next[j], pb.rays_next[n + j], pb.rays_next[2 * n + j]);
+                dir = mk3(pb.rays_next[3 * n + j], pb.rays_next[4 * n + j], pb.rays_next[5 * n + j]);
                 return true;
             }
             uint32_t s;
@@ -1112,8 +1128,7 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_bounce(TraceScene ts,
         },
         [&](uint32_t j, const HitRec& h) {
             if (j < n_next) {
-                const uint32_t s = next_queue[j];
-                pb.hit_t[s] = h.t; pb.hit_id0[s] = h.id0; pb.hit_id1[s] = h.id1; pb.hit_u[s] = h.u; pb.hit_v[s] = h.v;
+                pb.hit_t[j] = h.t; pb.hit_id0[j] = h.id0; pb.hit_id1[j] = h.id1; pb.hit_u[j] = h.u; pb.hit_v[j] = h.v;
             } else {
                 uint32_t s;
                 if (h.id1 < 0) q.state[entry(j, s)] = 2;
@@ -1128,11 +1143,12 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(PathBuffers pb, ShadowQ
     const uint32_t count = *d_count;
     const size_t n = pb.n, cap = q.cap;
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < count; i += gridDim.x * RT_BLOCK) {
-        const uint32_t s = queue[i];
+        const uint32_t pi = queue ? queue[i] : i;
+        const uint32_t s = pb.slot[pi];
         f3 Lp = mk3(pb.L[s], pb.L[n + s], pb.L[2 * n + s]);
         bool any = false;
         for (int l = 0; l < n_lights; ++l) {
-            const size_t e = (size_t)l * n + s;
+            const size_t e = (size_t)l * n + pi;
             if (q.state[e] != 2) continue;
             any = true;
             Lp = Lp + mk3(q.contrib[e], q.contrib[cap + e], q.contrib[2 * cap + e]);
