@@ -2,8 +2,9 @@
 // PathTracer::computeTile, src/cpu/PathTracer.cpp:17-164, that is not BVH
 // traversal): camera-ray generation, per-bounce shading with light sampling
 // and BSDF sampling, shadow-ray resolution, film accumulation.  Path state
-// is SoA, one slot per film pixel of this rank; stages talk through queues
-// of slot ids compacted with wave ballots (one atomic per wave).
+// is SoA; a slot is a film pixel of this rank in one pass of the batch, and
+// the paths alive at a bounce occupy consecutive indices of the state arrays
+// (compacted by k_shade with one atomic per workgroup).
 #pragma once
 #include "trace.h"
 
@@ -1081,8 +1082,9 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_shadow(TraceScene ts,
 }
 
 // One traversal launch per bounce: the closest-hit rays of the next bounce
-// (path queue `next_queue`, written by k_shade) and the shadow rays of this
-// bounce (work items (light, entry of `queue`)) are both ready once k_shade
+// (the first *d_next_count entries of the next-bounce arrays, written by
+// k_shade) and the shadow rays of this bounce (work items (light, path of
+// this bounce)) are both ready once k_shade
 // has run, so they share one persistent launch: item j < n_next is a
 // closest-hit ray, the others are shadow rays.
 template <bool EXACT>
