@@ -744,13 +744,13 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     if ((r = dev_alloc(c, &c->pb.status, n))) return r;
     if ((r = dev_alloc(c, &c->pb.film, (size_t)c->n_slots))) return r;
     HIP_TRY(c, hipMemset(c->pb.film, 0, (c->n_slots ? c->n_slots : 1) * sizeof(float4)));
-    HIP_TRY(c, hipMemset(c->pb.rays, 0, (n ? n : 1) * 6 * sizeof(float)));
+    if (n) HIP_TRY(c, hipMemset(c->pb.rays, 0, n * 6 * sizeof(float)));
     c->pb.slot_pixel = c->d_slot_pixel;
     c->pb.n = (uint32_t)n;
     c->pb.n1 = c->n_slots ? c->n_slots : 1;
     if (c->n_textures) {
         if ((r = dev_alloc(c, &c->d_duv, n))) return r;
-        HIP_TRY(c, hipMemset(c->d_duv, 0, (n ? n : 1) * sizeof(float4)));
+        HIP_TRY(c, hipMemset(c->d_duv, 0, (n ? n : 1) * sizeof(float4)));   // dev_alloc rounds an empty array up to one element
         c->ss.duv = c->d_duv;
     }
 

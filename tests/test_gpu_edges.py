@@ -241,3 +241,40 @@ def test_last_bounce_rays_match_oracle(cornell_env):
     assert np.array_equal(_bits(got[:3, ko]), _bits(ref[:3, kr]))
     assert np.abs(got[3:, ko] - ref[3:, kr]).max() < 1e-5
     assert scenes.bounce_rays(s, 40, 30, 2000).shape == (6, 2000)
+
+
+@pytest.mark.parametrize("depth", [1, 2])
+def test_no_lights_and_shallow_depths(cornell, depth):
+    """A scene without lights renders black where rays hit (nothing is ever
+    added, src/cpu/PathTracer.cpp:96) and the depth loop still runs; depth 1
+    has no bounce rays at all."""
+    dark = scenes.replace(cornell, lights=[])
+    ctx = Context(dark, 40, 24, max_depth=depth, seed=1, tile_size=8)
+    ctx.set_camera(dark.camera)
+    ctx.render(3)
+    film = ctx.read_film()
+    st = ctx.stats()
+    ctx.close()
+    ref, cnt = OracleScene(dark).render(dark.camera, 40, 24, depth, 1, 3, threads=2, tile_size=8)
+    assert np.array_equal(_bits(film), _bits(ref))
+    assert not film[..., :3].any() and st["shadow_rays"] == 0
+    # the oracle also counts the closest-hit ray of the last loop iteration, which the GPU does not trace
+    assert st["closest_rays"] <= cnt["closest"]
+    lit = Context(cornell, 40, 24, max_depth=depth, seed=1, tile_size=8)
+    lit.set_camera(cornell.camera)
+    lit.render(2)
+    ref, _ = OracleScene(cornell).render(cornell.camera, 40, 24, depth, 1, 2, threads=2, tile_size=8)
+    err = np.abs(lit.read_film()[..., :3] - ref[..., :3])
+    assert err.max() < 1e-5
+    lit.close()
+
+
+def test_more_ranks_than_tiles(cornell):
+    """A rank without tiles owns an empty slab and renders nothing."""
+    c = Context(cornell, 16, 16, max_depth=2, tile_size=16, rank=2, world=3)
+    c.set_camera(cornell.camera)
+    c.render(2)
+    assert not c.read_film().any()
+    assert c.stats()["n_local_pixels"] == 0 and c.film_slab_info()[2] == 0
+    assert c.last_bounce_rays().shape == (6, 0)
+    c.close()
