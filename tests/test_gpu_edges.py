@@ -278,3 +278,55 @@ def test_more_ranks_than_tiles(cornell):
     assert c.stats()["n_local_pixels"] == 0 and c.film_slab_info()[2] == 0
     assert c.last_bounce_rays().shape == (6, 0)
     c.close()
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 5), (2, 9)])
+def test_films_smaller_than_a_tile(cornell_env, w, h):
+    s = scenes.with_textures(cornell_env, uv_scale=2.0)
+    ctx = Context(s, w, h, max_depth=3, seed=2, tile_size=8)
+    ctx.set_camera(s.camera)
+    ctx.render(4)
+    film = ctx.read_film()
+    ctx.close()
+    ref, _ = OracleScene(s).render(s.camera, w, h, 3, 2, 4, threads=1, tile_size=8)
+    assert np.abs(film[..., :3] - ref[..., :3]).max() <= 1e-4 * max(1.0, float(np.abs(ref[..., :3]).max()))
+
+
+def test_many_lights_match_oracle(cornell):
+    """Light loop order and the per-light random-number slots with 24 lights of all three kinds."""
+    rng = np.random.default_rng(4)
+    lights = [scenes.Light(scenes.LIGHT_POINT, rng.uniform([-0.8, 0.3, -0.8], [0.8, 1.9, 0.8]).astype(np.float32),
+                           rng.uniform(0.05, 0.4, 3).astype(np.float32)) for _ in range(18)]
+    lights += scenes.area_quad((-0.3, 1.98, -0.3), (0.3, 1.98, -0.3), (0.3, 1.98, 0.3), (-0.3, 1.98, 0.3), (6.0, 5.0, 4.0))
+    lights += scenes.area_quad((-0.99, 0.5, 0.4), (-0.99, 0.5, -0.4), (-0.99, 1.4, -0.4), (-0.99, 1.4, 0.4), (2.0, 3.0, 5.0))
+    lights.insert(7, scenes.Light(scenes.LIGHT_ENV, intensity=np.ones(3, np.float32), env=scenes.sky_env(32, 16)))
+    lights.insert(15, scenes.Light(scenes.LIGHT_ENV, intensity=np.full(3, 0.5, np.float32), env=scenes.sky_env(16, 8, seed=3)))
+    s = scenes.replace(cornell, lights=lights)
+    ctx = Context(s, 48, 40, max_depth=3, seed=8, tile_size=8, batch=2)
+    ctx.set_camera(s.camera)
+    ctx.render(3)
+    film = ctx.read_film()
+    ctx.close()
+    ref, _ = OracleScene(s).render(s.camera, 48, 40, 3, 8, 3, threads=4, tile_size=8)
+    err = np.abs(film[..., :3] - ref[..., :3])
+    assert float(np.sqrt((err ** 2).mean()) / np.sqrt((ref[..., :3] ** 2).mean())) < 1e-4
+
+
+def test_degenerate_triangles_are_harmless():
+    """Zero-area and repeated-vertex triangles never report a hit (|det| < 1e-8,
+    src/scene/Ray.cpp) and do not disturb the tree or the hits around them."""
+    from tests.test_host_logic import _random_soup
+    s = _random_soup(300, 6)
+    idx = s.indices.copy()
+    idx[0:3] = idx[0]                 # a point
+    idx[3:6] = [idx[3], idx[4], idx[3]]   # a segment
+    s2 = scenes.replace(s, indices=idx)
+    ctx, orc = Context(s2, 16, 16), OracleScene(s2)
+    rays = scenes.incoherent_rays(s2, 30000, seed=12)
+    got, ref = ctx.trace_closest(rays), orc.intersect(rays)
+    for g, r in zip(got, ref):
+        assert np.array_equal(_bits(g), _bits(r))
+    assert not np.isin(got[2], [0, 3]).any()
+    for g, r in zip(ctx.get_bvh(), orc.bvh_nodes()):
+        assert g.shape == r.shape
+    ctx.close()
