@@ -147,6 +147,39 @@ def main():
             "ms_per_pass": r_el / args.render_passes * 1e3,
         }
 
+    # ---- tile-sharded leg (BASELINE.json configs[3] shape): ONE film split over the ranks by interleaved tiles,
+    # no exchange while rendering, one all-gather of the tile slabs over RCCL at read-out.  Strong scaling; it is a
+    # side report and must never take the headline down with it.
+    sharded = None
+    if use_dist and args.render_passes > 0 and (world > 1 or os.environ.get("BENCH_FORCE_SHARDED") == "1"):
+        try:
+            from raytracer_amd.dist import gather_film
+            SW, SH = 2 * W, 2 * H
+            sctx = Context(scene, SW, SH, max_depth=args.render_depth, seed=0, device=local_rank, rank=rank, world=world)
+            sctx.set_camera(scene.camera)
+            sctx.render(args.render_passes)  # warm-up
+            gather_film(sctx)
+            sctx.reset_accumulation()
+            barrier()
+            g0 = time.perf_counter()
+            sctx.render(args.render_passes)
+            sctx.synchronize()
+            g1 = time.perf_counter()
+            film = gather_film(sctx)
+            barrier()
+            g2 = time.perf_counter()
+            t = torch.tensor([g2 - g0, g2 - g1], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tot, gat = float(t[0].item()), float(t[1].item())
+            sharded = {"workload": f"sponza_class {SW}x{SH}, depth {args.render_depth}, {args.render_passes} passes, film sharded by "
+                                   f"64x64 tiles over {world} GPU(s), slabs all-gathered over RCCL", "scaling": "strong",
+                       "samples_per_sec": SW * SH * args.render_passes / tot, "ms_per_pass": tot / args.render_passes * 1e3,
+                       "gather_ms": gat * 1e3, "film_finite": bool(np.isfinite(film).all()),
+                       "film_mean": float(film[..., :3].mean())}
+            sctx.close()
+        except Exception as e:  # noqa: BLE001
+            sharded = {"error": repr(e)}
+
     if rank != 0:
         if use_dist:
             dist.destroy_process_group()
@@ -214,7 +247,7 @@ def main():
         "config": {"workload": f"primary-ray closest hit, sponza_class ({scene.n_triangles} triangles) {W}x{H}: "
                                f"coherent + incoherent + bounce sets of {n} rays each per GPU per step, one launch",
                    "rays_per_step": rays_per_step, "bvh": "reference LBVH, 1 triangle per leaf"},
-        "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "render": render,
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "sharded_render": sharded, "parity": parity, "render": render,
     }
     print(json.dumps(line))
     if use_dist:
