@@ -360,8 +360,10 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
             // ---- inner-node steps for the lanes standing on an inner node: several per vote for
             // closest-hit launches (the vote itself costs about a third of a step; measured +15 %),
             // one for launches with any-hit rays, which want their triangle tests early
+            // (giving the closest-hit waves of a mixed launch four steps too was measured: render 3.7 -> 4.4 ms)
+            const int reps = (ANY_HIT || MIXED) ? RT_INNER_REPS_ANY : RT_INNER_REPS;
 #pragma unroll 1
-            for (int rep = 0; rep < ((ANY_HIT || MIXED) ? RT_INNER_REPS_ANY : RT_INNER_REPS); ++rep) {
+            for (int rep = 0; rep < reps; ++rep) {
             if (have && cur >= 0) {
                 float4 a, b, c;
                 int32_t left, right;
