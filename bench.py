@@ -1,9 +1,9 @@
 """Headline benchmark: closest-hit BVH traversal on the 1080p Sponza-class
-scene, coherent (pinhole camera) + randomised incoherent ray sets, inputs
-resident in HBM (BASELINE.json configs[1]).
+scene, coherent (pinhole camera) + randomised incoherent + bounce ray sets,
+inputs resident in HBM (BASELINE.json configs[1]).
 
-One step = one launch of the closest-hit kernel over each of the two ray sets
-(2 x 2,073,600 rays).  With N > 1 every rank traces ray sets of that size on
+One step = ONE launch of the closest-hit kernel over the three ray sets
+(3 x 2,073,600 rays).  With N > 1 every rank traces ray sets of that size on
 its own GPU (scene replicated, no data-path collective): weak scaling.
 A second, untimed-for-`value` leg renders sample passes of the path tracer at
 1920x1080 and reports samples/s beside the headline.
@@ -24,6 +24,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+# fp32 vector peak in lane-operations/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (an FMA counts once: the path may
+# not contract, so every multiply and add is its own instruction)
+VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
 
 
 def algorithmic_bytes(n_rays: int, n_inner: int, n_tri: int) -> float:
@@ -31,6 +34,12 @@ def algorithmic_bytes(n_rays: int, n_inner: int, n_tri: int) -> float:
     24 B ray in + 20 B hit out per ray, 56 B per inner-node visit (two child
     boxes + two links), 36 B per triangle test (three positions)."""
     return 44.0 * n_rays + 56.0 * n_inner + 36.0 * n_tri
+
+
+def algorithmic_valu_ops(n_rays: int, n_inner: int, n_tri: int) -> float:
+    """fp32 lane-operations of the same algorithm: two slab tests (27 each) per inner-node visit, one
+    Moller-Trumbore test (57, the division counted as 10) per triangle test, 12 per ray for 1/dir."""
+    return 12.0 * n_rays + 54.0 * n_inner + 57.0 * n_tri
 
 
 def main():
@@ -231,8 +240,11 @@ def main():
                 traffic = json.load(open(tp)).get("k_trace_closest_bytes_per_launch")
             except Exception:
                 traffic = None
+        valu_tops = sum(algorithmic_valu_ops(n, counts[k]["n_inner"], counts[k]["n_tri"]) for k in counts) / (launch_ms * 1e-3) / 1e12
         roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    # the second candidate bound of this path, by the same convention (algorithmic work / launch time)
+                    "valu": {"achieved": valu_tops, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": valu_tops / VALU_PEAK_TOPS},
                     "bytes_per_launch": tot_bytes, "avg_launch_ms": launch_ms, "rays_per_launch": NS * n,
                     "per_set": {k: {"n_inner_per_ray": counts[k]["n_inner"] / n, "n_tri_per_ray": counts[k]["n_tri"] / n,
                                     "bytes_per_ray": algorithmic_bytes(n, counts[k]["n_inner"], counts[k]["n_tri"]) / n,

@@ -205,6 +205,11 @@ struct Counters {
     uint64_t n_inner = 0;  // inner nodes visited (2 child box tests each)
     uint64_t n_tri = 0;    // triangle tests
     uint64_t n_rays = 0;
+    // inner nodes entered as the far child of a pair although their box distance no longer beats the hit
+    // the near child's subtree produced; both of their child tests fail (a child box lies inside its
+    // parent's, and the slab arithmetic is monotonic), so they are the visits a traversal may skip
+    // without changing any result
+    uint64_t n_inner_stale = 0;
 };
 
 struct BVH {
@@ -334,9 +339,11 @@ struct BVH {
             if (leftStatus && rightStatus) {
                 if (right.dist < left.dist) {
                     intersectRec(ray, hit, rightNode, c);
+                    if (c && !leftNode.isLeaf && !(left.dist < hit.dist)) c->n_inner_stale++;
                     intersectRec(ray, hit, leftNode, c);
                 } else {
                     intersectRec(ray, hit, leftNode, c);
+                    if (c && !rightNode.isLeaf && !(right.dist < hit.dist)) c->n_inner_stale++;
                     intersectRec(ray, hit, rightNode, c);
                 }
             } else if (leftStatus)
