@@ -10,19 +10,17 @@
 //
 // Scheduling (free, because each lane's own sequence of steps is what fixes
 // the result): waves are persistent and pull rays in chunks from a global
-// counter; every loop iteration the wave votes and runs ONE of three bodies
-// for the lanes that want it -- refill idle lanes with new rays, one
-// inner-node step, or one triangle test -- so the inner and leaf bodies never
-// both issue for one iteration and lanes whose ray has finished do not idle
-// until the slowest ray of the wave is done.
+// counter; every loop iteration the wave runs up to three sections, each
+// behind a wave-uniform vote -- refill idle lanes with new rays, a few
+// inner-node steps, one triangle test -- so lanes whose ray has finished do
+// not idle until the slowest ray of the wave is done, and the triangle body
+// only issues when enough lanes wait for it.
 //
-// LDS (per 512-thread workgroup: 28 KB of nodes + 24 KB of stack, three
-// workgroups per CU):
+// LDS (per 1024-thread workgroup: 28 KB of nodes + 48 KB of stack, two
+// workgroups = 32 waves per CU):
 //  * the top of the tree: the inner nodes of levels 0..RT_TOP_LEVELS-1, which
-//    the builder stores at their heap index, as four SoA planes.  About half of all node visits land there;
-//    they were mostly L1 hits before, so the measured gain is small (a few
-//    percent on incoherent rays): what bounds the kernel is the rate at
-//    which the deep, cache-missing visits pull new lines from L2;
+//    the builder stores at their heap index, as four SoA planes.  About half
+//    of all node visits land there and cost no memory traffic;
 //  * the traversal stack: the first RT_STACK_LDS entries of each lane, laid
 //    out [level][thread] so a wave's access to any mix of levels is
 //    bank-conflict-free; deeper entries spill to a global buffer indexed by
@@ -102,48 +100,6 @@ RT_DEV bool slab_test_fast(f3 org, f3 inv, float bx0, float by0, float bz0, floa
     float tmax = fminf(fmaxf(lox, hix), fminf(fmaxf(loy, hiy), fmaxf(loz, hiz)));
     dist = tmin;
     return (tmin <= tmax) && (tmax > 0.0f);
-}
-
-// (Measured and not used by default, -DRT_PACKED_SLAB: wave64 packed fp32
-// operations issue at half rate on this part, the kernel came out 4 % slower.)
-// Both child boxes of a node at once with packed fp32 arithmetic: the twelve
-// subtractions and the twelve products become six v_pk_add_f32 and six
-// v_pk_mul_f32 (each lane of a packed operation rounds like the scalar one,
-// so the results are those of slab_test_fast bit for bit).  The ray keeps its
-// origin and inverse direction in the three pair orders the node layout asks
-// for: a = (lmin.x lmin.y | lmin.z lmax.x), b = (lmax.y lmax.z | rmin.x rmin.y),
-// c = (rmin.z rmax.x | rmax.y rmax.z).
-typedef float v2f __attribute__((ext_vector_type(2)));
-struct RayPk {
-    v2f o_xy, o_zx, o_yz, i_xy, i_zx, i_yz;
-};
-RT_DEV RayPk make_ray_pk(f3 org, f3 inv) {
-    RayPk r;
-    r.o_xy = (v2f){org.x, org.y}; r.o_zx = (v2f){org.z, org.x}; r.o_yz = (v2f){org.y, org.z};
-    r.i_xy = (v2f){inv.x, inv.y}; r.i_zx = (v2f){inv.z, inv.x}; r.i_yz = (v2f){inv.y, inv.z};
-    return r;
-}
-RT_DEV void slab2_fast_pk(const RayPk& r, float4 a, float4 b, float4 c, bool& ls, float& ld, bool& rs, float& rd) {
-    const v2f t0 = r.i_xy * ((v2f){a.x, a.y} - r.o_xy);   // left  lo.x lo.y
-    const v2f t1 = r.i_zx * ((v2f){a.z, a.w} - r.o_zx);   // left  lo.z hi.x
-    const v2f t2 = r.i_yz * ((v2f){b.x, b.y} - r.o_yz);   // left  hi.y hi.z
-    const v2f t3 = r.i_xy * ((v2f){b.z, b.w} - r.o_xy);   // right lo.x lo.y
-    const v2f t4 = r.i_zx * ((v2f){c.x, c.y} - r.o_zx);   // right lo.z hi.x
-    const v2f t5 = r.i_yz * ((v2f){c.z, c.w} - r.o_yz);   // right hi.y hi.z
-    {
-        const float lox = t0.x, loy = t0.y, loz = t1.x, hix = t1.y, hiy = t2.x, hiz = t2.y;
-        const float tmin = fmaxf(fminf(lox, hix), fmaxf(fminf(loy, hiy), fminf(loz, hiz)));
-        const float tmax = fminf(fmaxf(lox, hix), fminf(fmaxf(loy, hiy), fmaxf(loz, hiz)));
-        ld = tmin;
-        ls = (tmin <= tmax) && (tmax > 0.0f);
-    }
-    {
-        const float lox = t3.x, loy = t3.y, loz = t4.x, hix = t4.y, hiy = t5.x, hiz = t5.y;
-        const float tmin = fmaxf(fminf(lox, hix), fmaxf(fminf(loy, hiy), fminf(loz, hiz)));
-        const float tmax = fminf(fmaxf(lox, hix), fminf(fmaxf(loy, hiy), fmaxf(loz, hiz)));
-        rd = tmin;
-        rs = (tmin <= tmax) && (tmax > 0.0f);
-    }
 }
 
 // Per-lane traversal stack: levels below RT_STACK_LDS in LDS, the rest in
@@ -261,6 +217,20 @@ struct TraceWork {
 //
 // MIXED: closest-hit and any-hit rays in one launch; `load` says per item which
 // it is (and gives any-hit rays their far bound, +inf if none).
+//
+// Shape of the loop (it decides the instruction count: an earlier form with
+// `continue` on several paths and a per-lane `have` flag made the compiler
+// treat the loop as divergent and copy all ~20 state registers twice per
+// iteration, about one inner step's worth of VALU work):
+//  * a lane's state is `cur` alone: RT_IDLE = no ray, >= 0 = inner node,
+//    otherwise ~triangle slot;
+//  * the chunk bounds and the exhausted flag go through readfirstlane at the
+//    top of every iteration, so every vote is a scalar branch and the loop has
+//    one uniform back edge;
+//  * a finished ray's result stays in the lane's registers (`dirty`) and is
+//    written when the lane is refilled (or after the loop), which keeps the
+//    five result stores out of the inner-node and triangle sections.
+#define RT_IDLE ((int32_t)0x80000000)
 template <bool ANY_HIT, bool EXACT, bool BOUNDED = false, bool MIXED = false, typename Load, typename Done>
 RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* work, uint32_t* deferred, int32_t* lds_stack,
                              const TopTree& top, Load load, Done done) {
@@ -273,7 +243,6 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
     stk.lds = lds_stack + tid;
     stk.ovf = sc.ovf + gtid;
     stk.ovf_stride = sc.ovf_stride;
-
     // Items a wave takes from the shared counter at a time: RT_CHUNK when
     // there is plenty of work (few atomics, contiguous rays per wave), fewer
     // when the launch is small, so that a short queue spreads over many waves
@@ -281,43 +250,49 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
     const uint32_t per_wave = count / (gridDim.x * (RT_TBLOCK / 64));
     const uint32_t chunk = per_wave >= RT_CHUNK ? RT_CHUNK : (per_wave >= 64 ? 64 : (per_wave >= 32 ? 32 : 16));
 
-    bool have = false;         // this lane holds a ray
-    bool exhausted = false;    // wave-uniform: the work counter ran past count
+    bool dirty = false;        // the lane holds the result of a finished ray that is not yet written
+    int exhausted = 0;         // wave-uniform: the work counter ran past count
     uint32_t c_next = 0, c_end = 0;  // wave-uniform: the chunk of items this wave is handing out
     uint32_t item = 0;
-    int32_t cur = 0;
+    int32_t cur = RT_IDLE;
     int sp = 0;
     f3 org = mk3(0.f, 0.f, 0.f), dir = mk3(0.f, 0.f, 1.f), inv = mk3(0.f, 0.f, 1.f);
-#ifdef RT_PACKED_SLAB
-    RayPk pk = make_ray_pk(org, inv);
-#endif
     HitRec h;
     h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
     float tfar = inf;
     static_assert(!BOUNDED || ANY_HIT, "a far bound only makes sense for any-hit rays");
     static_assert(!MIXED || (!ANY_HIT && !BOUNDED), "MIXED takes the ray kind per item");
     bool any_lane = ANY_HIT;
+    constexpr int leaf_min = (ANY_HIT || MIXED) ? RT_LEAF_MIN_ANY : RT_LEAF_MIN;
+    constexpr int reps = (ANY_HIT || MIXED) ? RT_INNER_REPS_ANY : RT_INNER_REPS;
 
     for (;;) {
-        const unsigned long long m_idle = __ballot(!have);
+        // wave-uniform by construction; said again so that the votes compile to scalar branches
+        c_next = __builtin_amdgcn_readfirstlane(c_next);
+        c_end = __builtin_amdgcn_readfirstlane(c_end);
+        exhausted = __builtin_amdgcn_readfirstlane(exhausted);
+        const unsigned long long m_idle = __ballot(cur == RT_IDLE);
         const int n_idle = __popcll(m_idle);
         if (n_idle >= RT_REFILL_MIN && (c_next < c_end || !exhausted)) {
-            // ---- refill idle lanes from the wave's chunk; one atomic per
-            // chunk keeps the shared counter far from saturation and keeps a
-            // wave inside one contiguous run of rays
+            // ---- refill idle lanes from the wave's chunk; one atomic per chunk keeps the shared counter
+            // far from saturation and keeps a wave inside one contiguous run of rays
             if (c_next >= c_end) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(next, chunk);
-                base = __shfl(base, 0);
-                if (base >= count) { exhausted = true; continue; }
-                c_next = base;
-                c_end = (count - base < chunk) ? count : base + chunk;
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= count) {
+                    exhausted = 1;
+                } else {
+                    c_next = base;
+                    c_end = (count - base < chunk) ? count : base + chunk;
+                }
             }
-            const uint32_t avail = c_end - c_next;
-            const uint32_t k = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
-            if (!have) {
-                uint32_t r = __popcll(m_idle & ((1ull << lane) - 1ull));
-                if (r < k) {
+            if (c_next < c_end) {
+                const uint32_t avail = c_end - c_next;
+                const uint32_t k = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
+                const uint32_t r = __popcll(m_idle & ((1ull << lane) - 1ull));
+                if (cur == RT_IDLE && r < k) {
+                    if (dirty) { done(item, h); dirty = false; }
                     uint32_t i = c_next + r;
                     if (EXACT) i = deferred[i];
                     item = i;
@@ -326,9 +301,6 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     else if constexpr (BOUNDED) present = load(i, org, dir, tfar);
                     else present = load(i, org, dir);
                     inv = make_invdir(dir);
-#ifdef RT_PACKED_SLAB
-                    if (!EXACT) pk = make_ray_pk(org, inv);
-#endif
                     h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
                     float rd;
                     // root box test of src/scene/BVH.cpp:51-53
@@ -337,89 +309,78 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                         const bool tame = EXACT || (sc.tame && moderate(org.x) && moderate(org.y) && moderate(org.z) &&
                                                     moderate(inv.x) && moderate(inv.y) && moderate(inv.z));
                         if (tame) {
-                            have = true;
                             cur = sc.root_link;
                             sp = 0;
                         } else {
                             deferred[atomicAdd(&work->n_deferred, 1u)] = i;
                         }
                     } else {
-                        done(i, h);
+                        dirty = true;
+                    }
+                }
+                c_next += k;
+            }
+            continue;
+        }
+        if (n_idle == 64) break;   // nothing in flight and nothing left to fetch
+        if (__popcll(__ballot(cur < 0)) - n_idle < leaf_min && __ballot(cur >= 0) != 0ull) {
+            // ---- inner-node steps for the lanes standing on an inner node, unless enough lanes already wait
+            // at a leaf: several per vote for closest-hit launches, one for launches with any-hit rays, which
+            // want their triangle tests early
+#pragma unroll 1
+            for (int rep = 0; rep < reps; ++rep) {
+                if (cur >= 0) {
+                    float4 a, b, c;
+                    int32_t left, right;
+                    if (cur < top.n) {
+                        a = top.b0[cur]; b = top.b1[cur]; c = top.b2[cur];
+                        int2 l2 = top.lk[cur];
+                        left = l2.x; right = l2.y;
+                        // pins these as LDS reads: without it the compiler folds the two
+                        // branches into flat-address loads of a selected pointer
+                        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c.x), "+v"(c.y),
+                                     "+v"(c.z), "+v"(c.w), "+v"(left), "+v"(right));
+                    } else {
+                        const float4* np = sc.nodes + (size_t)cur * 4;
+                        a = np[0]; b = np[1]; c = np[2];
+                        float4 d = np[3];
+                        left = __float_as_int(d.x); right = __float_as_int(d.y);
+                    }
+                    float ld, rdist;
+                    bool ls, rs;
+                    if (EXACT) {
+                        ls = slab_test(org, inv, a.x, a.y, a.z, a.w, b.x, b.y, ld);
+                        rs = slab_test(org, inv, b.z, b.w, c.x, c.y, c.z, c.w, rdist);
+                    } else {
+                        ls = slab_test_fast(org, inv, a.x, a.y, a.z, a.w, b.x, b.y, ld);
+                        rs = slab_test_fast(org, inv, b.z, b.w, c.x, c.y, c.z, c.w, rdist);
+                    }
+                    const float bound = MIXED ? (any_lane ? tfar : h.t) : (BOUNDED ? tfar : h.t);
+                    ls = ls && (ld < bound);
+                    rs = rs && (rdist < bound);
+                    if (ls && rs) {
+                        const bool swap = rdist < ld;
+                        stk.push(sp, swap ? left : right);
+                        ++sp;
+                        cur = swap ? right : left;
+                    } else if (ls || rs) {
+                        cur = ls ? left : right;
+                    } else if (sp > 0) {
+                        --sp;
+                        cur = stk.pop(sp);
+                    } else {
+                        cur = RT_IDLE;
+                        dirty = true;
                     }
                 }
             }
-            c_next += k;
-            continue;
         }
-        if (n_idle == 64) break;  // nothing in flight and nothing left to fetch
-
-        const bool want_leaf = have && cur < 0;
-        const int n_leaf = __popcll(__ballot(want_leaf));
-        const int n_inner = 64 - n_idle - n_leaf;
-        if (n_inner > 0 && n_leaf < ((ANY_HIT || MIXED) ? RT_LEAF_MIN_ANY : RT_LEAF_MIN)) {
-            // ---- inner-node steps for the lanes standing on an inner node: several per vote for
-            // closest-hit launches (the vote itself costs about a third of a step; measured +15 %),
-            // one for launches with any-hit rays, which want their triangle tests early
-            // (giving the closest-hit waves of a mixed launch four steps too was measured: render 3.7 -> 4.4 ms)
-            const int reps = (ANY_HIT || MIXED) ? RT_INNER_REPS_ANY : RT_INNER_REPS;
-#pragma unroll 1
-            for (int rep = 0; rep < reps; ++rep) {
-            if (have && cur >= 0) {
-                float4 a, b, c;
-                int32_t left, right;
-                if (cur < top.n) {
-                    a = top.b0[cur]; b = top.b1[cur]; c = top.b2[cur];
-                    int2 l2 = top.lk[cur];
-                    left = l2.x; right = l2.y;
-                    // pins these as LDS reads: without it the compiler folds the two
-                    // branches into flat-address loads of a selected pointer
-#ifdef RT_PIN_MIN
-                    asm volatile("" : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(left));
-#else
-                    asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c.x), "+v"(c.y),
-                                 "+v"(c.z), "+v"(c.w), "+v"(left), "+v"(right));
-#endif
-                } else {
-                    const float4* np = sc.nodes + (size_t)cur * 4;
-                    a = np[0]; b = np[1]; c = np[2];
-                    float4 d = np[3];
-                    left = __float_as_int(d.x); right = __float_as_int(d.y);
-                }
-                float ld, rdist;
-                bool ls, rs;
-                if (EXACT) {
-                    ls = slab_test(org, inv, a.x, a.y, a.z, a.w, b.x, b.y, ld);
-                    rs = slab_test(org, inv, b.z, b.w, c.x, c.y, c.z, c.w, rdist);
-                } else {
-#ifdef RT_PACKED_SLAB
-                    slab2_fast_pk(pk, a, b, c, ls, ld, rs, rdist);
-#else
-                    ls = slab_test_fast(org, inv, a.x, a.y, a.z, a.w, b.x, b.y, ld);
-                    rs = slab_test_fast(org, inv, b.z, b.w, c.x, c.y, c.z, c.w, rdist);
-#endif
-                }
-                const float bound = MIXED ? (any_lane ? tfar : h.t) : (BOUNDED ? tfar : h.t);
-                ls = ls && (ld < bound);
-                rs = rs && (rdist < bound);
-                if (ls && rs) {
-                    const bool swap = rdist < ld;
-                    stk.push(sp, swap ? left : right);
-                    ++sp;
-                    cur = swap ? right : left;
-                } else if (ls || rs) {
-                    cur = ls ? left : right;
-                } else if (sp > 0) {
-                    --sp;
-                    cur = stk.pop(sp);
-                } else {
-                    have = false;
-                    done(item, h);
-                }
-            }
-            }
-        } else {
-            // ---- one triangle test for the lanes standing on a leaf
-            if (want_leaf) {
+        // ---- one triangle test for the lanes standing on a leaf, once enough of them wait there or no lane
+        // has an inner node left
+        const bool at_leaf = cur < 0 && cur != RT_IDLE;
+        const int n_leaf = __popcll(__ballot(at_leaf));
+        if (n_leaf >= leaf_min || (n_leaf > 0 && __ballot(cur >= 0) == 0ull)) {
+            if (at_leaf) {
                 const float4* tp = sc.tris + (size_t)(~cur) * 3;
                 float4 a = tp[0], b = tp[1], c = tp[2];
                 float t, u, v;
@@ -439,12 +400,13 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     --sp;
                     cur = stk.pop(sp);
                 } else {
-                    have = false;
-                    done(item, h);
+                    cur = RT_IDLE;
+                    dirty = true;
                 }
             }
         }
     }
+    if (dirty) done(item, h);
 }
 
 // Closest hit over a ray set (the batch form of BVH::intersect).  rays: 6
