@@ -16,8 +16,8 @@
 // not idle until the slowest ray of the wave is done, and the triangle body
 // only issues when enough lanes wait for it.
 //
-// LDS (per 1024-thread workgroup: 28 KB of nodes + 48 KB of stack, two
-// workgroups = 32 waves per CU):
+// LDS (per 1024-thread workgroup: 1023 nodes x 56 B = 56 KB of nodes + 24 KB
+// of stack; two workgroups = 32 waves per CU take 2 x 81,920 B, all 160 KB):
 //  * the top of the tree: the inner nodes of levels 0..RT_TOP_LEVELS-1, which
 //    the builder stores at their heap index, as four SoA planes.  About half
 //    of all node visits land there and cost no memory traffic;
@@ -32,13 +32,13 @@ namespace rt {
 
 #define RT_BLOCK 256        // shading kernels
 #ifndef RT_TBLOCK
-#define RT_TBLOCK 1024      // traversal kernels: 2 workgroups (32 waves) per CU share each top-tree copy
+#define RT_TBLOCK 1024      // traversal kernels: 2 workgroups (32 waves) per CU, each with its own top-tree copy
 #endif
 #ifndef RT_STACK_LDS
-#define RT_STACK_LDS 12
+#define RT_STACK_LDS 6
 #endif
 #ifndef RT_TOP_LEVELS
-#define RT_TOP_LEVELS 9     // tree levels whose inner nodes are kept in LDS (56 B per slot)
+#define RT_TOP_LEVELS 10    // tree levels whose inner nodes are kept in LDS (56 B per slot)
 #endif
 #define RT_TOP_NODES ((1 << RT_TOP_LEVELS) - 1)
 // vote thresholds (lanes of 64)
@@ -343,8 +343,8 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     } else {
                         const float4* np = sc.nodes + (size_t)cur * 4;
                         a = np[0]; b = np[1]; c = np[2];
-                        float4 d = np[3];
-                        left = __float_as_int(d.x); right = __float_as_int(d.y);
+                        const int2 d = *reinterpret_cast<const int2*>(np + 3);   // the other 8 bytes are padding
+                        left = d.x; right = d.y;
                     }
                     float ld, rdist;
                     bool ls, rs;
