@@ -216,7 +216,10 @@ def main():
             counts[k] = cnt
             bad_id = int((rid1 != gpu_id1[j * n:(j + 1) * n]).sum())
             bad_t = int((rt.view(np.uint32) != gpu_t[j * n:(j + 1) * n].view(np.uint32)).sum())
-            parity["per_set"][k] = {"id_mismatches": bad_id, "dist_bit_mismatches": bad_t, "hit_fraction": float((rid1 >= 0).mean())}
+            parity["per_set"][k] = {"id_mismatches": bad_id, "dist_bit_mismatches": bad_t, "hit_fraction": float((rid1 >= 0).mean()),
+                                    # triangle tests that tied the held hit exactly (first-visited wins on both sides)
+                                    "exact_distance_ties": int(cnt["n_ties"])}
+            parity["exact_distance_ties"] = parity.get("exact_distance_ties", 0) + int(cnt["n_ties"])
             parity["id_mismatches"] += bad_id
             parity["dist_bit_mismatches"] += bad_t
         cpu_baseline = {"value": cpu_reps * NS * n / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
@@ -234,15 +237,19 @@ def main():
         launch_ms = float(np.mean(kernel_ms))
         achieved = tot_bytes / (launch_ms * 1e-3) / 1e9
         traffic = None
+        counters = None   # pipe utilisation of the same kernel from the committed rocprofv3 --pmc passes
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             try:
-                traffic = json.load(open(tp)).get("k_trace_closest_bytes_per_launch")
+                tj = json.load(open(tp))
+                traffic = tj.get("k_trace_closest_bytes_per_launch")
+                counters = {k: tj[k] for k in ("tcc_hit_rate", "valu_issue_busy", "ta_busy", "valu_active_lane_fraction",
+                                               "valu_instructions_per_ray", "rocprof_avg_launch_us") if k in tj}
             except Exception:
                 traffic = None
         valu_tops = sum(algorithmic_valu_ops(n, counts[k]["n_inner"], counts[k]["n_tri"]) for k in counts) / (launch_ms * 1e-3) / 1e12
         roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "counters": counters,
                     # the second candidate bound of this path, by the same convention (algorithmic work / launch time)
                     "valu": {"achieved": valu_tops, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": valu_tops / VALU_PEAK_TOPS},
                     "bytes_per_launch": tot_bytes, "avg_launch_ms": launch_ms, "rays_per_launch": NS * n,

@@ -177,10 +177,10 @@ class OracleScene:
         n = rays.shape[1]
         t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
         id0 = np.empty(n, np.int32); id1 = np.empty(n, np.int32)
-        cnt = (C.c_uint64 * 4)()
+        cnt = (C.c_uint64 * 5)()
         self._L.orc_intersect(self._h, n, _f(rays), _f(t), _i(id0), _i(id1), _f(u), _f(v), cnt if counters else None, threads)
         if counters:
-            return t, id0, id1, u, v, {"n_inner": cnt[0], "n_tri": cnt[1], "n_rays": cnt[2], "n_inner_stale": cnt[3]}
+            return t, id0, id1, u, v, {"n_inner": cnt[0], "n_tri": cnt[1], "n_rays": cnt[2], "n_inner_stale": cnt[3], "n_ties": cnt[4]}
         return t, id0, id1, u, v
 
     def occluded(self, rays):

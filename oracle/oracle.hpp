@@ -210,6 +210,10 @@ struct Counters {
     // parent's, and the slab arithmetic is monotonic), so they are the visits a traversal may skip
     // without changing any result
     uint64_t n_inner_stale = 0;
+    // triangle tests that produced exactly the distance of the hit already held: the strict `<` of
+    // src/scene/BVH.cpp:139 keeps the first-visited triangle, so these are the ties whose resolution depends
+    // on the traversal order
+    uint64_t n_ties = 0;
 };
 
 struct BVH {
@@ -322,6 +326,7 @@ struct BVH {
                 if (c) c->n_tri++;
                 uint32_t i0 = indices[triId], i1 = indices[triId + 1], i2 = indices[triId + 2];
                 RayHit test = intersectTriangle(ray, vertices[i0].pos, vertices[i1].pos, vertices[i2].pos);
+                if (c && test.status && test.dist > 0.0001f && test.dist == hit.dist) c->n_ties++;
                 if (test.status && test.dist > 0.0001f && test.dist < hit.dist) {
                     hit = test;
                     hit.id1 = triId;

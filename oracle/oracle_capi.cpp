@@ -97,8 +97,8 @@ void orc_bvh_nodes(const orc_scene* o, float* boxes, int32_t* left, int32_t* rig
     }
 }
 
-// Rays: 6 SoA planes (ox,oy,oz,dx,dy,dz) of n floats.  counters[4] =
-// {inner nodes visited, triangle tests, rays, stale far-child visits} summed over the set (may be null).
+// Rays: 6 SoA planes (ox,oy,oz,dx,dy,dz) of n floats.  counters[5] =
+// {inner nodes visited, triangle tests, rays, stale far-child visits, exact-distance ties} summed over the set (may be null).
 void orc_intersect(const orc_scene* o, uint64_t n, const float* rays, float* t, int32_t* id0,
                    int32_t* id1, float* u, float* v, uint64_t* counters, int threads) {
     const float *ox = rays, *oy = rays + n, *oz = rays + 2 * n, *dx = rays + 3 * n, *dy = rays + 4 * n,
@@ -120,8 +120,8 @@ void orc_intersect(const orc_scene* o, uint64_t n, const float* rays, float* t, 
         for (auto& th : pool) th.join();
     }
     if (counters) {
-        counters[0] = counters[1] = counters[2] = counters[3] = 0;
-        for (auto& c : cs) { counters[0] += c.n_inner; counters[1] += c.n_tri; counters[2] += c.n_rays; counters[3] += c.n_inner_stale; }
+        counters[0] = counters[1] = counters[2] = counters[3] = counters[4] = 0;
+        for (auto& c : cs) { counters[0] += c.n_inner; counters[1] += c.n_tri; counters[2] += c.n_rays; counters[3] += c.n_inner_stale; counters[4] += c.n_ties; }
     }
 }
 

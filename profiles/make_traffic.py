@@ -30,6 +30,12 @@ def main(path):
         "correction": "FETCH_SIZE x1.0 (random 64-byte gathers: calibrated x1.03, profiles/r01/fetch_size_calibration.log); "
                       "WRITE_SIZE taken as is. Counter unit: KiB.",
         "tcc_hit_rate": hit / (hit + miss),
+        # pipe utilisation over the launch (cycles = GRBM_GUI_ACTIVE / 8 XCDs; a wave64 VALU instruction holds its
+        # SIMD for 4 cycles; TA_TA_BUSY summed over the 256 CUs)
+        "valu_issue_busy": c["SQ_INSTS_VALU"]["mean_per_launch"] * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0),
+        "ta_busy": c["TA_TA_BUSY_sum"]["mean_per_launch"] / (256.0 * c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0),
+        "valu_active_lane_fraction": c["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"]),
+        "valu_instructions_per_ray": c["SQ_INSTS_VALU"]["mean_per_launch"] / RAYS_PER_LAUNCH,
         "rocprof_avg_launch_us": d["kernels"][k]["avg_ns"] / 1e3,
         "rocprof_calls": d["kernels"][k]["calls"],
     }

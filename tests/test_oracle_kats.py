@@ -131,8 +131,10 @@ def test_equal_distance_tie_first_visited_wins():
     t0 = ((-1, -1, 0), (1, -1, 0), (0, 1, 0))
     s = soup([t0, t0], models=[0, 1])
     o = ob.OracleScene(s)
-    t, id0, id1, u, v = o.intersect(rays_of(((0.1, 0.05, 1), (0.01, 0.02, -1))))
+    t, id0, id1, u, v, cnt = o.intersect(rays_of(((0.1, 0.05, 1), (0.01, 0.02, -1))), counters=True)
     assert id1[0] == 0 and id0[0] == 0
+    # the second triangle is tested, gives exactly the same distance, and is counted as a tie
+    assert cnt["n_tri"] == 2 and cnt["n_ties"] == 1
 
 
 def test_identical_codes_split_at_midpoint():
