@@ -1125,3 +1125,11 @@ int rt_synchronize(rt_ctx* c) {
 }
 
 }  // extern "C"
+
+#ifdef RT_PROBE
+extern "C" int rt_debug_probe(unsigned long long* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rt::g_probe), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rt::g_probe), z, sizeof(z)) != hipSuccess) return 1; }
+    return 0;
+}
+#endif

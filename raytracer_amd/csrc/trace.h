@@ -46,13 +46,10 @@ namespace rt {
 #define RT_LB_WAVES , 8      // second launch bound: 8 waves per SIMD, i.e. at most 64 VGPRs
 #endif
 #ifndef RT_INNER_REPS
-#define RT_INNER_REPS 4      // inner-node steps per vote of the traversal loop, closest-hit launches
+#define RT_INNER_REPS 4      // inner-node steps per vote of the traversal loop
 #endif
 #ifndef RT_LEAF_MIN_ANY
 #define RT_LEAF_MIN_ANY 12   // leaf-step threshold of launches that carry any-hit rays
-#endif
-#ifndef RT_INNER_REPS_ANY
-#define RT_INNER_REPS_ANY 1  // the same for launches that carry any-hit rays (they want their leaf tests early)
 #endif
 #ifndef RT_REFILL_MIN
 #define RT_REFILL_MIN 20   // refill when at least this many lanes are idle
@@ -231,6 +228,14 @@ struct TraceWork {
 //    written when the lane is refilled (or after the loop), which keeps the
 //    five result stores out of the inner-node and triangle sections.
 #define RT_IDLE ((int32_t)0x80000000)
+#ifdef RT_PROBE
+// development probe (never in the shipped build): wave-step and lane-step counts of the loop's sections,
+// before and after the work counter ran dry
+__device__ unsigned long long g_probe[16];
+#define RT_PROBE_ADD(k, v) do { const unsigned long long pv_ = (unsigned long long)(v); if (lane == 0) atomicAdd(&g_probe[(k) + (exhausted ? 8 : 0)], pv_); } while (0)
+#else
+#define RT_PROBE_ADD(k, v) do { } while (0)
+#endif
 template <bool ANY_HIT, bool EXACT, bool BOUNDED = false, bool MIXED = false, typename Load, typename Done>
 RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* work, uint32_t* deferred, int32_t* lds_stack,
                              const TopTree& top, Load load, Done done) {
@@ -264,7 +269,6 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
     static_assert(!MIXED || (!ANY_HIT && !BOUNDED), "MIXED takes the ray kind per item");
     bool any_lane = ANY_HIT;
     constexpr int leaf_min = (ANY_HIT || MIXED) ? RT_LEAF_MIN_ANY : RT_LEAF_MIN;
-    constexpr int reps = (ANY_HIT || MIXED) ? RT_INNER_REPS_ANY : RT_INNER_REPS;
 
     for (;;) {
         // wave-uniform by construction; said again so that the votes compile to scalar branches
@@ -274,6 +278,7 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
         const unsigned long long m_idle = __ballot(cur == RT_IDLE);
         const int n_idle = __popcll(m_idle);
         if (n_idle >= RT_REFILL_MIN && (c_next < c_end || !exhausted)) {
+            RT_PROBE_ADD(0, 1); RT_PROBE_ADD(1, n_idle);
             // ---- refill idle lanes from the wave's chunk; one atomic per chunk keeps the shared counter
             // far from saturation and keeps a wave inside one contiguous run of rays
             if (c_next >= c_end) {
@@ -324,11 +329,12 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
         }
         if (n_idle == 64) break;   // nothing in flight and nothing left to fetch
         if (__popcll(__ballot(cur < 0)) - n_idle < leaf_min && __ballot(cur >= 0) != 0ull) {
-            // ---- inner-node steps for the lanes standing on an inner node, unless enough lanes already wait
-            // at a leaf: several per vote for closest-hit launches, one for launches with any-hit rays, which
-            // want their triangle tests early
+            // ---- a few inner-node steps for the lanes standing on an inner node, unless enough lanes already
+            // wait at a leaf
 #pragma unroll 1
-            for (int rep = 0; rep < reps; ++rep) {
+            for (int rep = 0; rep < RT_INNER_REPS; ++rep) {
+                RT_PROBE_ADD(2, 1); RT_PROBE_ADD(3, __popcll(__ballot(cur >= 0))); RT_PROBE_ADD(6, __popcll(__ballot(cur >= 0 && cur >= top.n)));
+                RT_PROBE_ADD(7, (__ballot(cur >= 0 && cur >= top.n) != 0ull) ? 1 : 0);
                 if (cur >= 0) {
                     float4 a, b, c;
                     int32_t left, right;
@@ -380,6 +386,7 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
         const bool at_leaf = cur < 0 && cur != RT_IDLE;
         const int n_leaf = __popcll(__ballot(at_leaf));
         if (n_leaf >= leaf_min || (n_leaf > 0 && __ballot(cur >= 0) == 0ull)) {
+            RT_PROBE_ADD(4, 1); RT_PROBE_ADD(5, n_leaf);
             if (at_leaf) {
                 const float4* tp = sc.tris + (size_t)(~cur) * 3;
                 float4 a = tp[0], b = tp[1], c = tp[2];
