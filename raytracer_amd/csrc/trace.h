@@ -58,7 +58,10 @@ namespace rt {
 #define RT_LEAF_MIN 12     // run a triangle step when at least this many lanes wait on a leaf
 #endif
 #ifndef RT_CHUNK
-#define RT_CHUNK 128       // items a wave takes from the shared counter at a time
+#define RT_CHUNK 128       // items a wave takes from a work counter at a time
+#endif
+#ifndef RT_XCD_RANGES
+#define RT_XCD_RANGES 2    // the items of a launch are cut into 8 x this many contiguous ranges
 #endif
 
 struct TraceScene {
@@ -189,10 +192,11 @@ RT_DEV TopTree stage_top_tree(const float4* nodes, int32_t n_nodes, char* lds) {
 
 // Work counters of one traversal launch (zeroed before the launch).
 struct TraceWork {
-    uint32_t next;         // next unclaimed item of the main launch
     uint32_t n_deferred;   // items handed to the exact launch
     uint32_t next_exact;   // next unclaimed entry of the deferred list
-    uint32_t pad;
+    uint32_t pad[14];
+    uint32_t next_x[8 * RT_XCD_RANGES * 16];  // next unclaimed item of each range of the main launch, relative to the
+                                              // range's start (one counter per 64-byte line)
 };
 
 // Persistent traversal of `count` work items.  `load(i, org, dir)` fetches
@@ -243,7 +247,7 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
     const uint32_t gtid = blockIdx.x * RT_TBLOCK + tid;
     const uint32_t lane = tid & 63u;
     const float inf = __builtin_inff();
-    uint32_t* next = EXACT ? &work->next_exact : &work->next;
+    uint32_t* next = &work->next_exact;   // EXACT launches: one counter over the deferred list
     LaneStack stk;
     stk.lds = lds_stack + tid;
     stk.ovf = sc.ovf + gtid;
@@ -257,6 +261,7 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
 
     bool dirty = false;        // the lane holds the result of a finished ray that is not yet written
     int exhausted = 0;         // wave-uniform: the work counter ran past count
+    uint32_t steal = 0;        // wave-uniform: ranges found empty so far (the XCD's own ranges come first)
     uint32_t c_next = 0, c_end = 0;  // wave-uniform: the chunk of items this wave is handing out
     uint32_t item = 0;
     int32_t cur = RT_IDLE;
@@ -275,6 +280,7 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
         c_next = __builtin_amdgcn_readfirstlane(c_next);
         c_end = __builtin_amdgcn_readfirstlane(c_end);
         exhausted = __builtin_amdgcn_readfirstlane(exhausted);
+        steal = __builtin_amdgcn_readfirstlane(steal);
         const unsigned long long m_idle = __ballot(cur == RT_IDLE);
         const int n_idle = __popcll(m_idle);
         if (n_idle >= RT_REFILL_MIN && (c_next < c_end || !exhausted)) {
@@ -282,15 +288,30 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
             // ---- refill idle lanes from the wave's chunk; one atomic per chunk keeps the shared counter
             // far from saturation and keeps a wave inside one contiguous run of rays
             if (c_next >= c_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(next, chunk);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= count) {
-                    exhausted = 1;
-                } else {
-                    c_next = base;
-                    c_end = (count - base < chunk) ? count : base + chunk;
+                // The items of the main launch are cut into 8 x RT_XCD_RANGES contiguous ranges with a counter each.
+                // Workgroups go to the eight XCDs round-robin, so workgroup b sits on XCD b % 8: its waves take
+                // chunks of that XCD's own ranges first, so an XCD's L2 sees a few compact parts of the ray set
+                // instead of all of it, and then help with the other XCDs' ranges.  (Were the mapping different
+                // the result would be the same, only the locality would be lost.)
+                const uint32_t n_ranges = EXACT ? 1u : 8u * RT_XCD_RANGES;
+                bool got = false;
+                while (!got && steal < n_ranges) {
+                    // an XCD's own ranges are x, x + 8, x + 16, ...: a mix of the whole launch
+                    const uint32_t x = EXACT ? 0u : (((blockIdx.x + steal / RT_XCD_RANGES) & 7u) + 8u * (steal % RT_XCD_RANGES));
+                    const uint32_t lo = (uint32_t)((unsigned long long)count * x / n_ranges);
+                    const uint32_t hi = (uint32_t)((unsigned long long)count * (x + 1) / n_ranges);
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(EXACT ? next : &work->next_x[x * 16], chunk);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base < hi - lo) {
+                        c_next = lo + base;
+                        c_end = (hi - lo - base < chunk) ? hi : lo + base + chunk;
+                        got = true;
+                    } else {
+                        ++steal;
+                    }
                 }
+                if (!got) exhausted = 1;
             }
             if (c_next < c_end) {
                 const uint32_t avail = c_end - c_next;
