@@ -125,6 +125,18 @@ void orc_intersect(const orc_scene* o, uint64_t n, const float* rays, float* t, 
     }
 }
 
+// Inner-node visits of every ray of a set (the length of each ray's traversal), for studying launch tails.
+void orc_intersect_visits(const orc_scene* o, uint64_t n, const float* rays, uint32_t* visits) {
+    const float *ox = rays, *oy = rays + n, *oz = rays + 2 * n, *dx = rays + 3 * n, *dy = rays + 4 * n,
+                *dz = rays + 5 * n;
+    for (uint64_t i = 0; i < n; ++i) {
+        Counters c;
+        Ray r({ox[i], oy[i], oz[i]}, {dx[i], dy[i], dz[i]});
+        o->s.bvh.intersect(r, &c);
+        visits[i] = (uint32_t)(c.n_inner + c.n_tri);
+    }
+}
+
 void orc_occluded(const orc_scene* o, uint64_t n, const float* rays, int32_t* status, uint64_t* counters) {
     const float *ox = rays, *oy = rays + n, *oz = rays + 2 * n, *dx = rays + 3 * n, *dy = rays + 4 * n,
                 *dz = rays + 5 * n;
