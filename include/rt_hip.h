@@ -179,6 +179,11 @@ int rt_copy_film_slab(rt_ctx* ctx, void* device_dst, uint64_t n_floats);
 int rt_unpack_slabs(int32_t width, int32_t height, int32_t tile_size, int32_t world,
                     const float* slabs_host, uint64_t slab_floats_per_rank, float* rgba_out);
 
+/* The same scatter on the device: d_slabs is the all-gathered buffer (rank-major, device memory), d_rgba_out a
+ * width*height*4 device film in the layout `Integrator::sync()` copies out (src/cpu/Integrator.cpp:21-24).  Runs on
+ * the context's stream and returns when it is done; width, height and tile size are the context's. */
+int rt_unpack_slabs_dev(rt_ctx* ctx, int32_t world, const float* d_slabs, uint64_t slab_floats_per_rank, float* d_rgba_out);
+
 /* Host-side inverse of rt_unpack_slabs for one rank: packs that rank's tiles
  * of a width*height*4 film into slab order.  rt_slab_floats gives the slab
  * size (floats) a rank holds.  Neither touches a device. */

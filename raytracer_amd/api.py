@@ -71,7 +71,7 @@ class rt_stats(C.Structure):
 
 EXPORTS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_set_camera", "rt_reset_accumulation", "rt_render",
-    "rt_read_film", "rt_film_slab", "rt_copy_film_slab", "rt_unpack_slabs", "rt_trace_closest",
+    "rt_read_film", "rt_film_slab", "rt_copy_film_slab", "rt_unpack_slabs", "rt_unpack_slabs_dev", "rt_trace_closest",
     "rt_trace_occluded", "rt_trace_closest_dev", "rt_trace_occluded_dev", "rt_get_bvh", "rt_get_stats",
     "rt_synchronize", "rt_version", "rt_lbvh_host", "rt_morton3d", "rt_last_trace_ms", "rt_slab_floats", "rt_pack_slab",
     "rt_read_primary_duv", "rt_trace_occluded_bounded", "rt_read_last_bounce_rays",
@@ -111,6 +111,7 @@ def load_library():
     lib.rt_film_slab.argtypes = [vp, C.POINTER(vp), up, C.POINTER(C.c_uint64)]
     lib.rt_copy_film_slab.argtypes = [vp, vp, C.c_uint64]
     lib.rt_unpack_slabs.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, fp, C.c_uint64, fp]
+    lib.rt_unpack_slabs_dev.argtypes = [vp, C.c_int32, vp, C.c_uint64, vp]
     lib.rt_trace_closest.argtypes = [vp, C.c_uint32, fp, fp, ip, ip, fp, fp]
     lib.rt_trace_occluded.argtypes = [vp, C.c_uint32, fp, ip]
     lib.rt_trace_occluded_bounded.argtypes = [vp, C.c_uint32, fp, fp, ip]
@@ -250,6 +251,11 @@ class Context:
 
     def copy_film_slab(self, device_ptr: int, n_floats: int):
         self._check(self._lib.rt_copy_film_slab(self._h, C.c_void_p(device_ptr), n_floats))
+
+    def unpack_slabs_dev(self, world: int, slabs_device_ptr: int, per_rank_floats: int, film_device_ptr: int):
+        """Scatters the all-gathered slabs (device memory) into a height*width*4 device film."""
+        self._check(self._lib.rt_unpack_slabs_dev(self._h, world, C.c_void_p(slabs_device_ptr), per_rank_floats,
+                                                  C.c_void_p(film_device_ptr)))
 
     # ---- BVH hooks
     def trace_closest(self, rays: np.ndarray):

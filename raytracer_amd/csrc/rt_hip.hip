@@ -958,6 +958,24 @@ int rt_unpack_slabs(int32_t W, int32_t H, int32_t tile, int32_t world, const flo
     return RT_OK;
 }
 
+int rt_unpack_slabs_dev(rt_ctx* c, int32_t world, const float* d_slabs, uint64_t per_rank, float* d_rgba_out) {
+    if (!c || !d_slabs || !d_rgba_out || world <= 0) return RT_ERR_ARG;
+    const int W = c->params.width, H = c->params.height, tile = c->tile;
+    const uint32_t n_tiles = (uint32_t)((W + tile - 1) / tile) * (uint32_t)((H + tile - 1) / tile);
+    // the largest slab must fit the stride the caller gathered with
+    if ((uint64_t)((n_tiles + world - 1) / world) * tile * tile * 4 > per_rank) {
+        c->err = "rt_unpack_slabs_dev: slab_floats_per_rank is smaller than a rank's slab";
+        return RT_ERR_ARG;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t n_pix = (uint32_t)W * (uint32_t)H;
+    hipLaunchKernelGGL(k_unpack_slabs, dim3((n_pix + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream,
+                       reinterpret_cast<const float4*>(d_slabs), per_rank / 4, reinterpret_cast<float4*>(d_rgba_out), W, H, tile, world);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
 uint64_t rt_slab_floats(int32_t W, int32_t H, int32_t tile, int32_t rank, int32_t world) {
     if (W <= 0 || H <= 0 || world <= 0 || rank < 0 || rank >= world) return 0;
     if (tile <= 0) tile = 64;

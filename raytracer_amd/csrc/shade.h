@@ -1190,4 +1190,19 @@ __global__ __launch_bounds__(RT_BLOCK) void k_film(PathBuffers pb, float first_f
     if (any) pb.film[s1] = p;
 }
 
+// Film assembly after the all-gather of the ranks' tile slabs: pixel (x, y) lies in tile t = ty * tiles_x + tx, which
+// rank t % world holds as its (t / world)-th tile, in 8x8 pixel blocks (the slot order of the tracer).
+__global__ __launch_bounds__(RT_BLOCK) void k_unpack_slabs(const float4* __restrict__ slabs, uint64_t per_rank4, float4* __restrict__ film,
+                                                          int W, int H, int tile, int world) {
+    const uint32_t p = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (p >= (uint32_t)W * (uint32_t)H) return;
+    const int x = (int)(p % (uint32_t)W), y = (int)(p / (uint32_t)W);
+    const int tiles_x = (W + tile - 1) / tile, bpr = tile / 8;
+    const int tx = x / tile, ty = y / tile, lx = x - tx * tile, ly = y - ty * tile;
+    const uint32_t t = (uint32_t)ty * tiles_x + tx;
+    const uint32_t rank = t % (uint32_t)world, k = t / (uint32_t)world;
+    const uint32_t i = (uint32_t)((ly >> 3) * bpr + (lx >> 3)) * 64u + (uint32_t)((ly & 7) * 8 + (lx & 7));
+    film[p] = slabs[(size_t)rank * per_rank4 + (size_t)k * tile * tile + i];
+}
+
 }  // namespace rt

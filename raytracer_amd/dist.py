@@ -27,11 +27,28 @@ def gather_slabs(local_slab: torch.Tensor, width: int, height: int, tile_size: i
     return unpack_slabs(width, height, tile_size, world, gathered.cpu().numpy(), per_rank)
 
 
-def gather_film(ctx: Context, group=None) -> np.ndarray:
-    """Gathers the tile-sharded film of a multi-rank render."""
+def gather_film_device(ctx: Context, group=None) -> torch.Tensor:
+    """Gathers the tile-sharded film of a multi-rank render and assembles it on the device: every rank ends up with
+    the (H, W, 4) film as a CUDA tensor.  One all-gather of the padded slabs, one scatter kernel, no host copy."""
+    world = dist.get_world_size(group)
     _, _, n_floats = ctx.film_slab_info()
     dev = torch.device("cuda", torch.cuda.current_device())
-    local = torch.empty(n_floats, dtype=torch.float32, device=dev)
+    per_rank = max(slab_floats(ctx.width, ctx.height, ctx.tile_size, r, world) for r in range(world))
+    local = torch.zeros(per_rank, dtype=torch.float32, device=dev)
     if n_floats:
         ctx.copy_film_slab(local.data_ptr(), n_floats)
-    return gather_slabs(local, ctx.width, ctx.height, ctx.tile_size, group)
+    gathered = torch.empty(world * per_rank, dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(gathered, local, group=group)
+    torch.cuda.synchronize(dev)   # the library's stream is not torch's
+    film = torch.empty((ctx.height, ctx.width, 4), dtype=torch.float32, device=dev)
+    ctx.unpack_slabs_dev(world, gathered.data_ptr(), per_rank, film.data_ptr())
+    return film
+
+
+def gather_film(ctx: Context, group=None) -> np.ndarray:
+    """Gathers the tile-sharded film of a multi-rank render into host memory (what the reference's
+    `Integrator::sync()` hands to the presenter, src/cpu/Integrator.cpp:21-24)."""
+    film = gather_film_device(ctx, group)
+    host = torch.empty(film.shape, dtype=torch.float32, pin_memory=True)
+    host.copy_(film)
+    return host.numpy()

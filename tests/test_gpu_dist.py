@@ -62,6 +62,14 @@ def test_rank_slabs_assemble_on_device(cornell_env):
         c.close()
     got = api.unpack_slabs(W, H, tile, world, gathered.cpu().numpy(), per_rank)
     assert np.array_equal(got, want)
+    # the same scatter on the device (what gather_film_device runs after the all-gather)
+    c = Context(s, W, H, max_depth=3, seed=5, tile_size=tile)
+    film = torch.full((H, W, 4), -1.0, dtype=torch.float32, device="cuda:0")
+    c.unpack_slabs_dev(world, gathered.data_ptr(), per_rank, film.data_ptr())
+    assert np.array_equal(film.cpu().numpy(), want)
+    with pytest.raises(api.RtError):
+        c.unpack_slabs_dev(world, gathered.data_ptr(), per_rank // 2, film.data_ptr())
+    c.close()
 
 
 def test_any_hit_agrees_with_closest_hit_at_full_size():
