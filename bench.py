@@ -42,6 +42,16 @@ def algorithmic_valu_ops(n_rays: int, n_inner: int, n_tri: int) -> float:
     return 12.0 * n_rays + 54.0 * n_inner + 57.0 * n_tri
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -223,6 +233,7 @@ def main():
             parity["id_mismatches"] += bad_id
             parity["dist_bit_mismatches"] += bad_t
         cpu_baseline = {"value": cpu_reps * NS * n / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                        "cpu_model": cpu_model(), "cores_available": len(os.sched_getaffinity(0)),
                         "sample": f"the full ray sets ({NS*n} rays) x {cpu_reps}, oracle closest hit, {threads} threads, {cpu_s:.1f} s wall"}
         if render is not None:
             # the oracle's integrator on a bounded sample of the render workload: one full-resolution pass
