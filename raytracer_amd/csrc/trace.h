@@ -9,8 +9,9 @@
 // decision and therefore every hit id equals the scalar path's.
 //
 // Scheduling (free, because each lane's own sequence of steps is what fixes
-// the result): waves are persistent and pull rays in chunks from a global
-// counter; every loop iteration the wave runs up to three sections, each
+// the result): waves are persistent and pull rays in chunks from the launch's
+// work counters (one per contiguous range of the ray set, the ranges dealt to
+// the XCDs); every loop iteration the wave runs up to three sections, each
 // behind a wave-uniform vote -- refill idle lanes with new rays, a few
 // inner-node steps, one triangle test -- so lanes whose ray has finished do
 // not idle until the slowest ray of the wave is done, and the triangle body
