@@ -704,12 +704,12 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         }
     }
     c->n_valid = (uint32_t)q0.size();
-    // ---- passes traced together: as many as asked for (default 8) within a
+    // ---- passes traced together: as many as asked for (default 16) within a
     // path-state budget of 48 GiB and 32-bit entry indices
     {
         const uint64_t L1 = (uint64_t)std::max<uint32_t>(1, sd->n_lights);
         const uint64_t per_slot = 170 + 45 * L1;   // bytes of path state and shadow entries per slot
-        uint64_t S = pr->batch ? pr->batch : 8;
+        uint64_t S = pr->batch ? pr->batch : 16;
         const uint64_t one = std::max<uint64_t>(1, (uint64_t)c->n_slots);
         S = std::min<uint64_t>(S, std::max<uint64_t>(1, (48ull << 30) / (per_slot * one)));
         S = std::min<uint64_t>(S, std::max<uint64_t>(1, 0x7FFFFFFFull / (L1 * one)));
