@@ -535,10 +535,16 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     const uint32_t ovf_levels = (uint32_t)std::max(1, c->bvh_max_depth + 2 - RT_STACK_LDS);
     const uint32_t ovf_stride = c->grid_trace * RT_TBLOCK;
     if ((r = dev_alloc(c, &c->d_ovf, (size_t)ovf_levels * ovf_stride))) return r;
+    // the traversal kernels address nodes (64 B) and triangles (48 B) with 32-bit byte offsets
+    if ((uint64_t)n_node_slots * 64ull > 0xFFFFFFFFull || (uint64_t)T * 48ull > 0xFFFFFFFFull) {
+        c->err = "scene too large: the node or triangle array reaches 4 GiB";
+        return RT_ERR_LIMIT;
+    }
     c->ts.nodes = c->d_nodes;
     c->ts.tris = c->d_tris;
     c->ts.root_link = root_link;
     c->ts.n_nodes = (int32_t)n_node_slots;
+    c->ts.n_tris = (int32_t)T;
     for (int k = 0; k < 3; ++k) { c->ts.rmin[k] = rmin[k]; c->ts.rmax[k] = rmax[k]; }
     c->ts.ovf = c->d_ovf;
     c->ts.ovf_stride = ovf_stride;

@@ -70,6 +70,7 @@ struct TraceScene {
     const float4* tris;    // 3 float4 per triangle (DevTri)
     int32_t root_link;
     int32_t n_nodes;       // node slots
+    int32_t n_tris;        // triangle slots
     float rmin[3], rmax[3];
     int32_t* ovf;          // overflow stack, [level - RT_STACK_LDS][grid thread]
     uint32_t ovf_stride;   // threads in the persistent grid
@@ -233,6 +234,13 @@ struct TraceWork {
 //    written when the lane is refilled (or after the loop), which keeps the
 //    five result stores out of the inner-node and triangle sections.
 #define RT_IDLE ((int32_t)0x80000000)
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// 16 bytes at byte offset `off` of a buffer resource
+RT_DEV float4 ldb128(__amdgpu_buffer_rsrc_t rs, int off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 #ifdef RT_PROBE
 // development probe (never in the shipped build): wave-step and lane-step counts of the loop's sections,
 // before and after the work counter ran dry
@@ -260,6 +268,10 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
     const uint32_t per_wave = count / (gridDim.x * (RT_TBLOCK / 64));
     const uint32_t chunk = per_wave >= RT_CHUNK ? RT_CHUNK : (per_wave >= 64 ? 64 : (per_wave >= 32 ? 32 : 16));
 
+    // nodes and triangles are fetched through buffer resources (32-bit byte offsets: the host refuses scenes whose
+    // arrays reach 4 GiB; a fetch past the end would read zeros instead of faulting)
+    const __amdgpu_buffer_rsrc_t rs_nodes = __builtin_amdgcn_make_buffer_rsrc((void*)sc.nodes, (short)0, (int)((uint32_t)sc.n_nodes * 64u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_tris = __builtin_amdgcn_make_buffer_rsrc((void*)sc.tris, (short)0, (int)((uint32_t)sc.n_tris * 48u), 0x00020000);
     bool dirty = false;        // the lane holds the result of a finished ray that is not yet written
     int exhausted = 0;         // wave-uniform: the work counter ran past count
     uint32_t steal = 0;        // wave-uniform: ranges found empty so far (the XCD's own ranges come first)
@@ -369,10 +381,11 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                         asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c.x), "+v"(c.y),
                                      "+v"(c.z), "+v"(c.w), "+v"(left), "+v"(right));
                     } else {
-                        const float4* np = sc.nodes + (size_t)cur * 4;
-                        a = np[0]; b = np[1]; c = np[2];
-                        const int2 d = *reinterpret_cast<const int2*>(np + 3);   // the other 8 bytes are padding
-                        left = d.x; right = d.y;
+                        // through a buffer resource: one 32-bit offset instead of a 64-bit address per lane
+                        const int off = cur << 6;
+                        a = ldb128(rs_nodes, off); b = ldb128(rs_nodes, off + 16); c = ldb128(rs_nodes, off + 32);
+                        const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rs_nodes, off + 48, 0, 0);   // the other 8 bytes are padding
+                        left = (int32_t)d.x; right = (int32_t)d.y;
                     }
                     float ld, rdist;
                     bool ls, rs;
@@ -410,8 +423,8 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
         if (n_leaf >= leaf_min || (n_leaf > 0 && __ballot(cur >= 0) == 0ull)) {
             RT_PROBE_ADD(4, 1); RT_PROBE_ADD(5, n_leaf);
             if (at_leaf) {
-                const float4* tp = sc.tris + (size_t)(~cur) * 3;
-                float4 a = tp[0], b = tp[1], c = tp[2];
+                const int toff = (~cur) * 48;
+                float4 a = ldb128(rs_tris, toff), b = ldb128(rs_tris, toff + 16), c = ldb128(rs_tris, toff + 32);
                 float t, u, v;
                 bool finished = false;
                 if (tri_test(org, dir, mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y), mk3(b.z, b.w, c.x), t, u, v)) {
