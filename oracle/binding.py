@@ -28,6 +28,27 @@ def build():
     subprocess.check_call(["make", "-C", _DIR, "-s"])
 
 
+def set_math(mode: str):
+    """"libm" (default: what the reference calls) or "shared" (the fixed polynomials the HIP kernels restate, under
+    which films are comparable bit for bit).  Process-wide."""
+    lib().orc_set_math({"libm": 0, "shared": 1}[mode])
+
+
+def get_math() -> str:
+    return "shared" if lib().orc_get_math() else "libm"
+
+
+def dm_eval(which: str, x, y=None) -> np.ndarray:
+    """Evaluates one of the shared-mode functions (sin, cos, acos, atan2(x, y), log2) over float32 arrays."""
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(x if y is None else y, np.float32)
+    out = np.empty_like(x)
+    fp = C.POINTER(C.c_float)
+    lib().orc_dm_eval(["sin", "cos", "acos", "atan2", "log2"].index(which), x.size, x.ctypes.data_as(fp), y.ctypes.data_as(fp),
+                      out.ctypes.data_as(fp))
+    return out
+
+
 def lib():
     global _lib
     if _lib is not None:
@@ -41,6 +62,8 @@ def lib():
     L.orc_create.argtypes = [C.c_uint32, fp, fp, fp, fp, fp, C.c_uint32, up, ip, C.c_uint32, fp, C.c_uint32,
                              C.POINTER(orc_light_desc), ip, C.c_uint32, C.POINTER(orc_texture_desc), ip]
     L.orc_occluded_bounded.argtypes = [vp, C.c_uint64, fp, fp, ip]
+    L.orc_set_math.argtypes = [C.c_int]
+    L.orc_dm_eval.argtypes = [C.c_int, C.c_uint64, fp, fp, fp]
     for name in ("orc_erf_inv", "orc_erf_poly"):
         getattr(L, name).restype = C.c_float
         getattr(L, name).argtypes = [C.c_float]

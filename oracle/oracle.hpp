@@ -58,6 +58,78 @@ inline float gmax(float x, float y) { return (x < y) ? y : x; }
 inline vec3 gmin(vec3 a, vec3 b) { return {gmin(a.x, b.x), gmin(a.y, b.y), gmin(a.z, b.z)}; }
 inline vec3 gmax(vec3 a, vec3 b) { return {gmax(a.x, b.x), gmax(a.y, b.y), gmax(a.z, b.z)}; }
 inline vec3 normalize(vec3 v) { return v * (1.0f / std::sqrt(dot(v, v))); }
+
+// ---------------------------------------------------------------- transcendentals
+// The reference calls libm (std::sin/cos/acos/atan2, and log2 stands in for Mango's lod); libm's last bits differ
+// from one C library to the next and from the GPU's device library, so a film can only be compared with a
+// tolerance.  Mode 1 swaps the five functions for fixed single-precision polynomials (Cephes-style: Cody-Waite
+// reduction, minimax polynomials, only + - * / sqrt and integer steps, each a single IEEE operation), which the
+// HIP kernels restate operation for operation: in that mode a film is comparable bit for bit.  Mode 0 (libm) is
+// the default and is what the CPU baseline times; tests bound the distance between the two modes.
+inline int& mathMode() { static int mode = 0; return mode; }
+
+namespace dm {
+inline float fromBits(uint32_t b) { float f; std::memcpy(&f, &b, 4); return f; }
+inline uint32_t toBits(float f) { uint32_t b; std::memcpy(&b, &f, 4); return b; }
+// sine and cosine of |x| < 1e4 (this path's arguments lie in [-pi/4, 2 pi]); NaN otherwise
+inline void sincos(float x, float& s, float& c) {
+    const float ax = std::fabs(x);
+    if (!(ax < 1e4f)) { s = c = fromBits(0x7FC00000u); return; }
+    int j = (int)(ax * 1.27323954473516f);   // multiples of pi/4, rounded up to even
+    j += (j & 1);
+    const float y = (float)j;
+    const float r = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    const float z = r * r;
+    const float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    const float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    const int q = (j >> 1) & 3;              // |x| = r + q * pi/2
+    const float sa = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
+    c = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+    s = (x < 0.0f) ? -sa : sa;
+}
+inline float sin(float x) { float s, c; sincos(x, s, c); return s; }
+inline float cos(float x) { float s, c; sincos(x, s, c); return c; }
+inline float asinPoly(float x) {   // |x| <= 0.5
+    const float z = x * x;
+    return ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * x + x;
+}
+inline float acos(float x) {       // x in [-1, 1]
+    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * asinPoly(std::sqrt(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * asinPoly(std::sqrt(0.5f * (1.0f - x)));
+    return 1.57079632679489661923f - asinPoly(x);
+}
+inline float atanPos(float x) {    // x >= 0 (inf included)
+    float y0 = 0.0f;
+    if (x > 2.414213562373095f) { y0 = 1.57079632679489661923f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y0 = 0.78539816339744830962f; x = (x - 1.0f) / (x + 1.0f); }
+    const float z = x * x;
+    return y0 + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
+}
+inline float atan2(float y, float x) {   // (-pi, pi]; atan2(0, 0) = 0 whatever the signs of the zeros
+    const float ax = std::fabs(x), ay = std::fabs(y);
+    if (ax == 0.0f && ay == 0.0f) return 0.0f;
+    float a = atanPos(ay / ax);
+    if (x < 0.0f) a = 3.14159265358979323846f - a;
+    return (y < 0.0f) ? -a : a;
+}
+inline float log2(float x) {             // positive normal x; +inf gives 128
+    const uint32_t b = toBits(x);
+    int e = (int)(b >> 23) - 127;
+    float m = fromBits((b & 0x007FFFFFu) | 0x3F800000u);   // [1, 2)
+    if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f, z = f * f;
+    float y = ((((((((7.0376836292e-2f * f - 1.1514610310e-1f) * f + 1.1676998740e-1f) * f - 1.2420140846e-1f) * f + 1.4249322787e-1f) * f -
+                  1.6668057665e-1f) * f + 2.0000714765e-1f) * f - 2.4999993993e-1f) * f + 3.3333331174e-1f) * f * z;
+    y = y - 0.5f * z;
+    return (float)e + (f + y) * 1.44269504088896341f;
+}
+}  // namespace dm
+
+inline float msin(float x) { return mathMode() ? dm::sin(x) : std::sin(x); }
+inline float mcos(float x) { return mathMode() ? dm::cos(x) : std::cos(x); }
+inline float macos(float x) { return mathMode() ? dm::acos(x) : std::acos(x); }
+inline float matan2(float y, float x) { return mathMode() ? dm::atan2(y, x) : std::atan2(y, x); }
+inline float mlog2(float x) { return mathMode() ? dm::log2(x) : std::log2(x); }
 inline float length2(vec3 v) { return dot(v, v); }
 inline bool is_zero(vec3 v) { return v.x == 0.0f && v.y == 0.0f && v.z == 0.0f; }
 
@@ -471,7 +543,7 @@ inline vec2 concentricSampleDisk(vec2 u) {
         r = uo.y;
         theta = PI_OVER_2 - PI_OVER_4 * (uo.x / uo.y);
     }
-    return {r * std::cos(theta), r * std::sin(theta)};
+    return {r * mcos(theta), r * msin(theta)};
 }
 // src/bsdf/Samples.hpp:30-34 — the cosine-weighted "up" goes into y
 inline vec3 cosineSampleHemisphere(vec2 u) {
@@ -480,9 +552,9 @@ inline vec3 cosineSampleHemisphere(vec2 u) {
     return {d.x, z, d.y};
 }
 // src/bsdf/Samples.hpp:36-43
-inline float sphericalTheta(vec3 v) { return std::acos(clampf(v.y, -1.f, 1.f)); }
+inline float sphericalTheta(vec3 v) { return macos(clampf(v.y, -1.f, 1.f)); }
 inline float sphericalPhi(vec3 v) {
-    float p = std::atan2(-v.z, -v.x);
+    float p = matan2(-v.z, -v.x);
     return (p < 0.f) ? (p + 2.f * (float)M_PI) : p;
 }
 
@@ -603,8 +675,8 @@ enum GlossyKind { GLOSSY_NONE = 0, GLOSSY_BECKMANN = 1, GLOSSY_GGX = 2 };
 inline void beckmannSample11(float cosThetaI, float U1, float U2, float* slope_x, float* slope_y) {
     if ((double)cosThetaI > .9999) {
         float r = std::sqrt(-std::log(1.0f - U1));
-        float sinPhi = std::sin(2 * (float)M_PI * U2);
-        float cosPhi = std::cos(2 * (float)M_PI * U2);
+        float sinPhi = msin(2 * (float)M_PI * U2);
+        float cosPhi = mcos(2 * (float)M_PI * U2);
         *slope_x = r * cosPhi;
         *slope_y = r * sinPhi;
         return;
@@ -614,7 +686,7 @@ inline void beckmannSample11(float cosThetaI, float U1, float U2, float* slope_x
     float cotThetaI = 1 / tanThetaI;
     float a = -1, c = erfPoly(cotThetaI);
     float sample_x = std::max(U1, (float)1e-6f);
-    float thetaI = std::acos(cosThetaI);
+    float thetaI = macos(cosThetaI);
     float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
     float b = c - (1 + c) * std::pow(1 - sample_x, fit);
     const float SQRT_PI_INV = 1.f / std::sqrt((float)M_PI);
@@ -640,8 +712,8 @@ inline void ggxSample11(float cosTheta, float U1, float U2, float* slope_x, floa
     if ((double)cosTheta > .9999) {
         float r = std::sqrt(U1 / (1 - U1));
         float phi = 6.28318530718f * U2;
-        *slope_x = r * std::cos(phi);
-        *slope_y = r * std::sin(phi);
+        *slope_x = r * mcos(phi);
+        *slope_y = r * msin(phi);
         return;
     }
     float sinTheta = std::sqrt(std::max((float)0, (float)1 - cosTheta * cosTheta));
@@ -984,8 +1056,8 @@ struct Light {
         pdf = 0.0f;
         if (mapPdf == 0) return {0.f, 0.f, 0.f};
         float theta = uv.x * (float)M_PI, phi = uv.y * 2.f * (float)M_PI;
-        float cosT = std::cos(theta), sinT = std::sin(theta);
-        float sinP = std::sin(phi), cosP = std::cos(phi);
+        float cosT = mcos(theta), sinT = msin(theta);
+        float sinP = msin(phi), cosP = mcos(phi);
         in = {sinT * cosP, sinT * sinP, cosT};
         pdf = mapPdf / (2 * (float)M_PI * (float)M_PI * sinT);
         if (!std::isfinite(pdf)) pdf = 0.0f;
@@ -1001,7 +1073,7 @@ struct Light {
             return std::isfinite(p) ? p : 0;
         }
         float theta = sphericalTheta(inW), phi = sphericalPhi(inW);
-        float sinT = std::sin(theta);
+        float sinT = msin(theta);
         if (sinT == 0) return 0;
         return dist.pdf({phi * INV_2PI, theta * INV_PI}) / (2 * (float)M_PI * (float)M_PI * sinT);
     }
@@ -1072,7 +1144,7 @@ struct Texture {
         float rho = (lx < ly) ? ly : lx;
         const int last = (int)levels.size() - 1;
         float lod = 0.0f;
-        if (rho > 1.0f) lod = std::log2(rho);  // false for NaN
+        if (rho > 1.0f) lod = mlog2(rho);  // false for NaN
         if (!(lod < (float)last)) lod = (float)last;
         int l0 = (int)std::floor(lod);
         int l1 = std::min(l0 + 1, last);

@@ -125,6 +125,23 @@ void orc_intersect(const orc_scene* o, uint64_t n, const float* rays, float* t, 
     }
 }
 
+// 0 = libm (default), 1 = the fixed single-precision polynomials the HIP kernels restate (bit-comparable films).
+// Process-wide; not to be switched while a render is running.
+void orc_set_math(int mode) { mathMode() = mode ? 1 : 0; }
+int orc_get_math() { return mathMode(); }
+// the five functions of mode 1, for accuracy tests: which = 0 sin, 1 cos, 2 acos, 3 atan2(x, y), 4 log2
+void orc_dm_eval(int which, uint64_t n, const float* x, const float* y, float* out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        switch (which) {
+            case 0: out[i] = dm::sin(x[i]); break;
+            case 1: out[i] = dm::cos(x[i]); break;
+            case 2: out[i] = dm::acos(x[i]); break;
+            case 3: out[i] = dm::atan2(x[i], y[i]); break;
+            default: out[i] = dm::log2(x[i]); break;
+        }
+    }
+}
+
 // Inner-node visits of every ray of a set (the length of each ray's traversal), for studying launch tails.
 void orc_intersect_visits(const orc_scene* o, uint64_t n, const float* rays, uint32_t* visits) {
     const float *ox = rays, *oy = rays + n, *oz = rays + 2 * n, *dx = rays + 3 * n, *dy = rays + 4 * n,

@@ -41,6 +41,64 @@ RT_DEV float power_heuristic(float fPdf, float gPdf) {
     return (f * f) / (f * f + g * g);
 }
 
+// Transcendentals.  The reference calls libm, whose last bits no device library reproduces; the kernels use fixed
+// single-precision polynomials instead (Cephes-style: Cody-Waite reduction, minimax polynomials), every step one
+// IEEE operation, so that a CPU restatement of the same steps yields the same bits and films can be compared
+// exactly.  Accuracy against the exact functions: sin/cos 1.5 ulp (absolute 8e-8 near their zeros), acos 1.3 ulp,
+// atan2 3.1 ulp, log2 1.7 ulp.
+// sine and cosine of |x| < 1e4 (this path's arguments lie in [-pi/4, 2 pi]); NaN otherwise
+RT_DEV void dm_sincos(float x, float& s, float& c) {
+    const float ax = fabsf(x);
+    if (!(ax < 1e4f)) { s = c = __uint_as_float(0x7FC00000u); return; }
+    int j = (int)(ax * 1.27323954473516f);   // multiples of pi/4, rounded up to even
+    j += (j & 1);
+    const float y = (float)j;
+    const float r = ((ax - y * 0.78515625f) - y * 2.4187564849853515625e-4f) - y * 3.77489497744594108e-8f;
+    const float z = r * r;
+    const float ps = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
+    const float pc = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
+    const int q = (j >> 1) & 3;              // |x| = r + q * pi/2
+    const float sa = (q == 0) ? ps : (q == 1) ? pc : (q == 2) ? -ps : -pc;
+    c = (q == 0) ? pc : (q == 1) ? -ps : (q == 2) ? -pc : ps;
+    s = (x < 0.0f) ? -sa : sa;
+}
+RT_DEV float dm_sin(float x) { float s, c; dm_sincos(x, s, c); return s; }
+RT_DEV float dm_cos(float x) { float s, c; dm_sincos(x, s, c); return c; }
+RT_DEV float dm_asin_poly(float x) {   // |x| <= 0.5
+    const float z = x * x;
+    return ((((4.2163199048e-2f * z + 2.4181311049e-2f) * z + 4.5470025998e-2f) * z + 7.4953002686e-2f) * z + 1.6666752422e-1f) * z * x + x;
+}
+RT_DEV float dm_acos(float x) {        // x in [-1, 1]
+    if (x < -0.5f) return 3.14159265358979323846f - 2.0f * dm_asin_poly(sqrtf(0.5f * (1.0f + x)));
+    if (x > 0.5f) return 2.0f * dm_asin_poly(sqrtf(0.5f * (1.0f - x)));
+    return 1.57079632679489661923f - dm_asin_poly(x);
+}
+RT_DEV float dm_atan_pos(float x) {    // x >= 0 (inf included)
+    float y0 = 0.0f;
+    if (x > 2.414213562373095f) { y0 = 1.57079632679489661923f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y0 = 0.78539816339744830962f; x = (x - 1.0f) / (x + 1.0f); }
+    const float z = x * x;
+    return y0 + ((((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z * x + x);
+}
+RT_DEV float dm_atan2(float y, float x) {   // (-pi, pi]; atan2(0, 0) = 0 whatever the signs of the zeros
+    const float ax = fabsf(x), ay = fabsf(y);
+    if (ax == 0.0f && ay == 0.0f) return 0.0f;
+    float a = dm_atan_pos(ay / ax);
+    if (x < 0.0f) a = 3.14159265358979323846f - a;
+    return (y < 0.0f) ? -a : a;
+}
+RT_DEV float dm_log2(float x) {             // positive normal x; +inf gives 128
+    const uint32_t b = __float_as_uint(x);
+    int e = (int)(b >> 23) - 127;
+    float m = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);   // [1, 2)
+    if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f, z = f * f;
+    float y = ((((((((7.0376836292e-2f * f - 1.1514610310e-1f) * f + 1.1676998740e-1f) * f - 1.2420140846e-1f) * f + 1.4249322787e-1f) * f -
+                  1.6668057665e-1f) * f + 2.0000714765e-1f) * f - 2.4999993993e-1f) * f + 3.3333331174e-1f) * f * z;
+    y = y - 0.5f * z;
+    return (float)e + (f + y) * 1.44269504088896341f;
+}
+
 // Counter-based sampler: one draw is a pure function of (seed, pixel, pass,
 // dimension).  Stands in for the per-tile std::mt19937(std::random_device())
 // of src/cpu/PathTracer.cpp:20-22, which no run can reproduce.

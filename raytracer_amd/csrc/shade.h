@@ -154,7 +154,7 @@ RT_DEV f2 concentric_sample_disk(f2 u) {
         r = uo.y;
         theta = kPiOver2 - kPiOver4 * (uo.x / uo.y);
     }
-    f2 o; o.x = r * cosf(theta); o.y = r * sinf(theta);
+    f2 o; o.x = r * dm_cos(theta); o.y = r * dm_sin(theta);
     return o;
 }
 // src/bsdf/Samples.hpp:30-34: the cosine-weighted axis is written to y
@@ -164,9 +164,9 @@ RT_DEV f3 cosine_sample_hemisphere(f2 u) {
     return mk3(d.x, z, d.y);
 }
 // src/bsdf/Samples.hpp:36-43
-RT_DEV float spherical_theta(f3 v) { return acosf(clampf(v.y, -1.f, 1.f)); }
+RT_DEV float spherical_theta(f3 v) { return dm_acos(clampf(v.y, -1.f, 1.f)); }
 RT_DEV float spherical_phi(f3 v) {
-    float p = atan2f(-v.z, -v.x);
+    float p = dm_atan2(-v.z, -v.x);
     return (p < 0.f) ? (p + 2.f * kPi) : p;
 }
 
@@ -280,8 +280,8 @@ RT_DEV float erf_poly(float x) {
 RT_DEV void beckmann_sample11(float cosThetaI, float U1, float U2, float& slope_x, float& slope_y) {
     if ((double)cosThetaI > .9999) {
         float r = sqrtf(-logf(1.0f - U1));
-        float sinPhi = sinf(2 * kPi * U2);
-        float cosPhi = cosf(2 * kPi * U2);
+        float sinPhi = dm_sin(2 * kPi * U2);
+        float cosPhi = dm_cos(2 * kPi * U2);
         slope_x = r * cosPhi;
         slope_y = r * sinPhi;
         return;
@@ -291,7 +291,7 @@ RT_DEV void beckmann_sample11(float cosThetaI, float U1, float U2, float& slope_
     float cotThetaI = 1 / tanThetaI;
     float a = -1, c = erf_poly(cotThetaI);
     float sample_x = gmax(U1, 1e-6f);
-    float thetaI = acosf(cosThetaI);
+    float thetaI = dm_acos(cosThetaI);
     float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
     float b = c - (1 + c) * powf(1 - sample_x, fit);
     const float SQRT_PI_INV = 1.f / sqrtf(kPi);
@@ -317,8 +317,8 @@ RT_DEV void ggx_sample11(float cosTheta, float U1, float U2, float& slope_x, flo
     if ((double)cosTheta > .9999) {
         float r = sqrtf(U1 / (1 - U1));
         float phi = 6.28318530718f * U2;
-        slope_x = r * cosf(phi);
-        slope_y = r * sinf(phi);
+        slope_x = r * dm_cos(phi);
+        slope_y = r * dm_sin(phi);
         return;
     }
     float sinTheta = sqrtf(gmax(0.f, 1.f - cosTheta * cosTheta));
@@ -601,7 +601,7 @@ RT_DEV f3 tex_trilinear(const ShadeScene& sc, const DevTexture t, f2 uv, float4 
     float rho = (lx < ly) ? ly : lx;
     const int last = t.n_levels - 1;
     float lod = 0.0f;
-    if (rho > 1.0f) lod = log2f(rho);
+    if (rho > 1.0f) lod = dm_log2(rho);
     if (!(lod < (float)last)) lod = (float)last;
     int l0 = (int)floorf(lod);
     int l1 = min(l0 + 1, last);
@@ -668,8 +668,8 @@ RT_DEV f3 light_sample(const DevLight& l, f3 p, f2 u, f3& in, float& pdf, float&
     in = mk3(0.f, 0.f, 0.f);
     if (mapPdf == 0) return mk3(0.f, 0.f, 0.f);
     float theta = d0 * kPi, phi = d1 * 2.f * kPi;
-    float cosT = cosf(theta), sinT = sinf(theta);
-    float sinP = sinf(phi), cosP = cosf(phi);
+    float cosT = dm_cos(theta), sinT = dm_sin(theta);
+    float sinP = dm_sin(phi), cosP = dm_cos(phi);
     in = mk3(sinT * cosP, sinT * sinP, cosT);
     pdf = mapPdf / (2 * kPi * kPi * sinT);
     if (!isfinite(pdf)) pdf = 0.0f;
@@ -688,7 +688,7 @@ RT_DEV float light_pdf(const DevLight& l, f3 p, f3 inW) {
         return isfinite(pd) ? pd : 0;
     }
     float theta = spherical_theta(inW), phi = spherical_phi(inW);
-    float sinT = sinf(theta);
+    float sinT = dm_sin(theta);
     if (sinT == 0) return 0.f;
     float p0 = phi * kInv2Pi, p1 = theta * kInvPi;
     int iu = (int)clampf((float)(int)(p0 * l.H), 0.f, (float)(l.H - 1));

@@ -1,0 +1,57 @@
+"""Films bit for bit.  With the oracle's transcendentals switched to the fixed polynomials the kernels restate
+(oracle.binding.set_math("shared")), nothing on the reference path (Oren-Nayar BSDF, point / environment lights,
+textures) differs between the two sides any more, so the film of the HIP tracer must equal the oracle's exactly,
+NaN for NaN.  (The distance between the shared-math and the libm oracle is bounded in test_oracle_math.py; the
+glossy lobe still calls exp / log / pow and keeps its tolerance.)"""
+import numpy as np
+import pytest
+
+from raytracer_amd import Context, scenes
+from oracle import binding as ob
+from oracle.binding import OracleScene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def shared_math():
+    ob.set_math("shared")
+    yield
+    ob.set_math("libm")
+
+
+def _exact(scene, W, H, depth, seed, passes, **kw):
+    ctx, orc = Context(scene, W, H, max_depth=depth, seed=seed, **kw), OracleScene(scene)
+    ctx.set_camera(scene.camera)
+    ctx.render(passes)
+    film = ctx.read_film()
+    ref, _ = orc.render(scene.camera, W, H, depth, seed, passes)
+    ctx.close()
+    same = (film.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(film) & np.isnan(ref))
+    assert same.all(), f"{(~same).any(-1).sum()} of {W * H} pixels differ; max abs {np.nanmax(np.abs(film - ref))}"
+    assert np.isfinite(film[..., :3]).all() and film[..., :3].max() > 0
+
+
+def test_cornell_point_light(cornell):
+    _exact(cornell, 128, 128, 4, 1, 3)
+
+
+def test_cornell_env_and_point(cornell_env):
+    _exact(cornell_env, 100, 70, 4, 2, 3, tile_size=32)
+    _exact(cornell_env, 64, 64, 8, 7, 5, batch=2)
+
+
+def test_atrium_depth8(atrium_small):
+    _exact(atrium_small, 160, 96, 8, 5, 2)
+
+
+def test_textured_atrium(atrium_small):
+    _exact(scenes.with_textures(atrium_small, uv_scale=8.0), 160, 96, 4, 3, 2)
+
+
+def test_many_lights(cornell):
+    rng = np.random.default_rng(4)
+    lights = [scenes.Light(scenes.LIGHT_POINT, rng.uniform([-0.8, 0.2, -0.8], [0.8, 1.9, 0.8]).astype(np.float32),
+                           np.full(3, 0.6, np.float32)) for _ in range(9)]
+    lights.append(scenes.Light(scenes.LIGHT_ENV, intensity=np.array([1.0, 1.0, 1.0], np.float32), env=scenes.sky_env(64, 32)))
+    _exact(scenes.replace(cornell, lights=lights), 96, 96, 4, 9, 2)
