@@ -55,3 +55,20 @@ def test_many_lights(cornell):
                            np.full(3, 0.6, np.float32)) for _ in range(9)]
     lights.append(scenes.Light(scenes.LIGHT_ENV, intensity=np.array([1.0, 1.0, 1.0], np.float32), env=scenes.sky_env(64, 32)))
     _exact(scenes.replace(cornell, lights=lights), 96, 96, 4, 9, 2)
+
+
+def test_ggx_lobe_and_area_lights(atrium_small):
+    # the GGX lobe needs no exp / log / pow, so it is exact as well (the Beckmann lobe keeps its tolerance,
+    # tests/test_gpu_glossy_area.py)
+    panel = scenes.area_quad((-6, 14.5, -3), (6, 14.5, -3), (6, 14.5, 3), (-6, 14.5, 3), (60.0, 55.0, 45.0))
+    s = scenes.with_glossy(scenes.replace(atrium_small, lights=atrium_small.lights + panel), scenes.GLOSSY_GGX)
+    _exact(s, 120, 68, 6, 4, 2)
+
+
+def test_ragged_film_and_odd_tiles(cornell_env):
+    for w, h, tile in ((100, 70, 64), (65, 129, 32), (7, 5, 8)):
+        _exact(cornell_env, w, h, 3, 11, 2, tile_size=tile)
+
+
+def test_larger_film_many_passes(atrium_small):
+    _exact(atrium_small, 480, 270, 8, 1, 3)
