@@ -244,6 +244,18 @@ def main():
             render["cpu_baseline"] = {"samples_per_sec": rw * rh / c1, "mrays_per_sec": (rc["closest"] + rc["shadow"]) / c1 / 1e6,
                                       "cores": threads, "kind": "port",
                                       "sample": f"1 pass at {rw}x{rh}, depth {args.render_depth}, {c1:.1f} s wall"}
+            # full-size film parity: one pass of the GPU tracer against one pass of the oracle with its transcendentals
+            # switched to the polynomials the kernels restate ("shared" mode), compared bit for bit
+            from oracle import binding as oracle_binding
+            ctx.reset_accumulation()
+            ctx.render(1)
+            g_film = ctx.read_film()
+            oracle_binding.set_math("shared")
+            o_film, _ = orc.render(scene.camera, rw, rh, args.render_depth, 0, 1, threads=threads)
+            oracle_binding.set_math("libm")
+            same = (g_film.view(np.uint32) == o_film.view(np.uint32)) | (np.isnan(g_film) & np.isnan(o_film))
+            render["film_parity"] = {"passes": 1, "pixels": rw * rh, "bit_identical": bool(same.all()),
+                                     "pixels_differing": int((~same).any(-1).sum())}
         tot_bytes = sum(algorithmic_bytes(n, counts[k]["n_inner"], counts[k]["n_tri"]) for k in counts)
         launch_ms = float(np.mean(kernel_ms))
         achieved = tot_bytes / (launch_ms * 1e-3) / 1e9
