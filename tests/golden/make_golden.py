@@ -42,8 +42,30 @@ def glossy_area():
     np.savez_compressed(os.path.join(HERE, "cornell_area_ggx_24.npz"), **out)
 
 
+def shared_films():
+    # 6. films rendered with the oracle's transcendentals in "shared" mode (the polynomials the HIP kernels
+    # restate): the GPU must reproduce these bit for bit
+    ob.set_math("shared")
+    try:
+        out = {}
+        s = scenes.cornell_box(env=True)
+        out["cornell_env_32"], _ = ob.OracleScene(s).render(s.camera, 32, 32, 4, 0, 2, threads=1)
+        s = scenes.with_textures(scenes.cornell_box(env=True), uv_scale=3.0)
+        out["cornell_tex_30x26"], _ = ob.OracleScene(s).render(s.camera, 30, 26, 3, 5, 2, threads=1, tile_size=16)
+        s = scenes.cornell_area(glossy=scenes.GLOSSY_GGX)
+        out["cornell_area_ggx_24"], _ = ob.OracleScene(s).render(s.camera, 24, 24, 3, 2, 2, threads=1)
+        a = scenes.sponza_class(detail=0.2, env_size=(32, 16))
+        out["atrium_d02_48x27"], _ = ob.OracleScene(a).render(a.camera, 48, 27, 6, 3, 2, threads=1)
+        np.savez_compressed(os.path.join(HERE, "films_shared_math.npz"), **out)
+    finally:
+        ob.set_math("libm")
+
+
 def main():
     L = ob.lib()
+    if "--only-shared-films" in sys.argv:
+        shared_films()
+        return
     if "--only-textured" in sys.argv:
         textured()
         return
@@ -77,6 +99,7 @@ def main():
                         n_inner=np.uint64(c["n_inner"]), n_tri=np.uint64(c["n_tri"]))
     textured()
     glossy_area()
+    shared_films()
     print("golden vectors written to", HERE)
 
 

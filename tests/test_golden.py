@@ -83,3 +83,37 @@ def test_gpu_reproduces_atrium_golden():
     assert np.array_equal(id1, g["id1"]) and np.array_equal(id0, g["id0"])
     assert np.array_equal(bits(t), bits(g["t"])) and np.array_equal(bits(v), bits(g["v"]))
     ctx.close()
+
+
+# ---- films in the oracle's "shared" math mode: reproduced bit for bit by both sides
+SHARED_CASES = {
+    "cornell_env_32": (lambda: scenes.cornell_box(env=True), 32, 32, 4, 0, 2, {}),
+    "cornell_tex_30x26": (lambda: scenes.with_textures(scenes.cornell_box(env=True), uv_scale=3.0), 30, 26, 3, 5, 2, {"tile_size": 16}),
+    "cornell_area_ggx_24": (lambda: scenes.cornell_area(glossy=scenes.GLOSSY_GGX), 24, 24, 3, 2, 2, {}),
+    "atrium_d02_48x27": (lambda: scenes.sponza_class(detail=0.2, env_size=(32, 16)), 48, 27, 6, 3, 2, {}),
+}
+
+
+def test_oracle_reproduces_shared_math_films():
+    g = np.load(os.path.join(G, "films_shared_math.npz"))
+    ob.set_math("shared")
+    try:
+        for key, (mk, W, H, depth, seed, passes, kw) in SHARED_CASES.items():
+            s = mk()
+            film, _ = ob.OracleScene(s).render(s.camera, W, H, depth, seed, passes, threads=2, **kw)
+            assert np.array_equal(bits(film), bits(g[key])), key
+    finally:
+        ob.set_math("libm")
+
+
+@pytest.mark.gpu
+def test_gpu_reproduces_shared_math_films():
+    """No oracle at run time: the HIP tracer against the committed films, bit for bit."""
+    g = np.load(os.path.join(G, "films_shared_math.npz"))
+    for key, (mk, W, H, depth, seed, passes, kw) in SHARED_CASES.items():
+        s = mk()
+        ctx = Context(s, W, H, max_depth=depth, seed=seed, **kw)
+        ctx.set_camera(s.camera)
+        ctx.render(passes)
+        assert np.array_equal(bits(ctx.read_film()), bits(g[key])), key
+        ctx.close()
