@@ -39,12 +39,12 @@ def get_math() -> str:
 
 
 def dm_eval(which: str, x, y=None) -> np.ndarray:
-    """Evaluates one of the shared-mode functions (sin, cos, acos, atan2(x, y), log2) over float32 arrays."""
+    """Evaluates one of the shared-mode functions (sin, cos, acos, atan2(x, y), log2, log, exp, pow(x, y)) over float32 arrays."""
     x = np.ascontiguousarray(x, np.float32)
     y = np.ascontiguousarray(x if y is None else y, np.float32)
     out = np.empty_like(x)
     fp = C.POINTER(C.c_float)
-    lib().orc_dm_eval(["sin", "cos", "acos", "atan2", "log2"].index(which), x.size, x.ctypes.data_as(fp), y.ctypes.data_as(fp),
+    lib().orc_dm_eval(["sin", "cos", "acos", "atan2", "log2", "log", "exp", "pow"].index(which), x.size, x.ctypes.data_as(fp), y.ctypes.data_as(fp),
                       out.ctypes.data_as(fp))
     return out
 

@@ -64,7 +64,8 @@ inline vec3 normalize(vec3 v) { return v * (1.0f / std::sqrt(dot(v, v))); }
 // from one C library to the next and from the GPU's device library, so a film can only be compared with a
 // tolerance.  Mode 1 swaps the five functions for fixed single-precision polynomials (Cephes-style: Cody-Waite
 // reduction, minimax polynomials, only + - * / sqrt and integer steps, each a single IEEE operation), which the
-// HIP kernels restate operation for operation: in that mode a film is comparable bit for bit.  Mode 0 (libm) is
+// HIP kernels restate operation for operation (exp, log and pow of the microfacet lobe included): in that mode a
+// film is comparable bit for bit.  Mode 0 (libm) is
 // the default and is what the CPU baseline times; tests bound the distance between the two modes.
 inline int& mathMode() { static int mode = 0; return mode; }
 
@@ -123,8 +124,46 @@ inline float log2(float x) {             // positive normal x; +inf gives 128
     y = y - 0.5f * z;
     return (float)e + (f + y) * 1.44269504088896341f;
 }
+// natural logarithm of x >= 0 (zero gives -inf, denormals are scaled up first); NaN for negative x and NaN
+inline float log(float x) {
+    if (!(x >= 0.0f)) return fromBits(0x7FC00000u);
+    if (x == 0.0f) return -std::numeric_limits<float>::infinity();
+    if (!(x < std::numeric_limits<float>::infinity())) return x;
+    int e = 0;
+    if (x < 1.17549435e-38f) { x = x * 8388608.0f; e = -23; }
+    const uint32_t b = toBits(x);
+    e += (int)(b >> 23) - 127;
+    float m = fromBits((b & 0x007FFFFFu) | 0x3F800000u);   // [1, 2)
+    if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f, z = f * f, fe = (float)e;
+    float y = ((((((((7.0376836292e-2f * f - 1.1514610310e-1f) * f + 1.1676998740e-1f) * f - 1.2420140846e-1f) * f + 1.4249322787e-1f) * f -
+                  1.6668057665e-1f) * f + 2.0000714765e-1f) * f - 2.4999993993e-1f) * f + 3.3333331174e-1f) * f * z;
+    y = y + -2.12194440e-4f * fe;
+    y = y - 0.5f * z;
+    return (f + y) + 0.693359375f * fe;
+}
+inline float pow2i(int k) { return fromBits((uint32_t)(k + 127) << 23); }   // 2^k, k in [-126, 127]
+// e^x: +inf above 88.72, 0 below -103.9 (-inf included); NaN for NaN
+inline float exp(float x) {
+    if (x != x) return x;
+    if (x > 88.72283905206835f) return std::numeric_limits<float>::infinity();
+    if (x < -103.9f) return 0.0f;
+    const float n = std::floor(1.44269504088896341f * x + 0.5f);
+    x = x - n * 0.693359375f;
+    x = x - n * -2.12194440e-4f;
+    const float z = x * x;
+    const float p = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x + 4.1665795894e-2f) * x + 1.6666665459e-1f) * x +
+                     5.0000001201e-1f) * z + x + 1.0f;
+    const int k = (int)n, k1 = k / 2;
+    return p * pow2i(k1) * pow2i(k - k1);
+}
+// x^y for x >= 0 as exp(y log x) (the lobe raises a number of (0, 1] to a power near 1)
+inline float pow(float x, float y) { return exp(y * log(x)); }
 }  // namespace dm
 
+inline float mlog(float x) { return mathMode() ? dm::log(x) : std::log(x); }
+inline float mexp(float x) { return mathMode() ? dm::exp(x) : std::exp(x); }
+inline float mpow(float x, float y) { return mathMode() ? dm::pow(x, y) : std::pow(x, y); }
 inline float msin(float x) { return mathMode() ? dm::sin(x) : std::sin(x); }
 inline float mcos(float x) { return mathMode() ? dm::cos(x) : std::cos(x); }
 inline float macos(float x) { return mathMode() ? dm::acos(x) : std::acos(x); }
@@ -630,7 +669,7 @@ inline float sin2Phi(vec3 w) { return sinPhi(w) * sinPhi(w); }              // :
 inline float erfInv(float x) {
     float w, p;
     x = clampf(x, -.99999f, .99999f);
-    w = -std::log((1 - x) * (1 + x));
+    w = -mlog((1 - x) * (1 + x));
     if (w < 5) {
         w = w - 2.5f;
         p = 2.81022636e-08f;
@@ -665,7 +704,7 @@ inline float erfPoly(float x) {
     if (x < 0) sign = -1;
     x = std::fabs(x);
     float t = 1 / (1 + p * x);
-    float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * std::exp(-x * x);
+    float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * mexp(-x * x);
     return sign * y;
 }
 
@@ -674,7 +713,7 @@ enum GlossyKind { GLOSSY_NONE = 0, GLOSSY_BECKMANN = 1, GLOSSY_GGX = 2 };
 // src/bsdf/Microfacet.cpp:7-80 (Beckmann) with erfInv restored
 inline void beckmannSample11(float cosThetaI, float U1, float U2, float* slope_x, float* slope_y) {
     if ((double)cosThetaI > .9999) {
-        float r = std::sqrt(-std::log(1.0f - U1));
+        float r = std::sqrt(-mlog(1.0f - U1));
         float sinPhi = msin(2 * (float)M_PI * U2);
         float cosPhi = mcos(2 * (float)M_PI * U2);
         *slope_x = r * cosPhi;
@@ -688,14 +727,14 @@ inline void beckmannSample11(float cosThetaI, float U1, float U2, float* slope_x
     float sample_x = std::max(U1, (float)1e-6f);
     float thetaI = macos(cosThetaI);
     float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
-    float b = c - (1 + c) * std::pow(1 - sample_x, fit);
+    float b = c - (1 + c) * mpow(1 - sample_x, fit);
     const float SQRT_PI_INV = 1.f / std::sqrt((float)M_PI);
-    float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * std::exp(-cotThetaI * cotThetaI));
+    float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * mexp(-cotThetaI * cotThetaI));
     int it = 0;
     while (++it < 10) {
         if (!(b >= a && b <= c)) b = 0.5f * (a + c);
         float invErf = erfInv(b);
-        float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * std::exp(-invErf * invErf)) - sample_x;
+        float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * mexp(-invErf * invErf)) - sample_x;
         float derivative = normalization * (1 - invErf * tanThetaI);
         if (std::fabs(value) < 1e-5f) break;
         if (value > 0)
@@ -751,7 +790,7 @@ struct Microfacet {
         if (std::isinf(t2)) return 0.f;
         float cos4Theta = cos2Theta(wh) * cos2Theta(wh);
         if (kind == GLOSSY_BECKMANN)
-            return std::exp(-t2 * (cos2Phi(wh) / (alphax * alphax) + sin2Phi(wh) / (alphay * alphay))) /
+            return mexp(-t2 * (cos2Phi(wh) / (alphax * alphax) + sin2Phi(wh) / (alphay * alphay))) /
                    ((float)M_PI * alphax * alphay * cos4Theta);
         float e = (cos2Phi(wh) / (alphax * alphax) + sin2Phi(wh) / (alphay * alphay)) * t2;
         return 1 / ((float)M_PI * alphax * alphay * cos4Theta * (1 + e) * (1 + e));

@@ -129,7 +129,7 @@ void orc_intersect(const orc_scene* o, uint64_t n, const float* rays, float* t, 
 // Process-wide; not to be switched while a render is running.
 void orc_set_math(int mode) { mathMode() = mode ? 1 : 0; }
 int orc_get_math() { return mathMode(); }
-// the five functions of mode 1, for accuracy tests: which = 0 sin, 1 cos, 2 acos, 3 atan2(x, y), 4 log2
+// the functions of mode 1, for accuracy tests: which = 0 sin, 1 cos, 2 acos, 3 atan2(x, y), 4 log2, 5 log, 6 exp, 7 pow(x, y)
 void orc_dm_eval(int which, uint64_t n, const float* x, const float* y, float* out) {
     for (uint64_t i = 0; i < n; ++i) {
         switch (which) {
@@ -137,7 +137,10 @@ void orc_dm_eval(int which, uint64_t n, const float* x, const float* y, float* o
             case 1: out[i] = dm::cos(x[i]); break;
             case 2: out[i] = dm::acos(x[i]); break;
             case 3: out[i] = dm::atan2(x[i], y[i]); break;
-            default: out[i] = dm::log2(x[i]); break;
+            case 4: out[i] = dm::log2(x[i]); break;
+            case 5: out[i] = dm::log(x[i]); break;
+            case 6: out[i] = dm::exp(x[i]); break;
+            default: out[i] = dm::pow(x[i], y[i]); break;
         }
     }
 }

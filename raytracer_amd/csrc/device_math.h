@@ -45,7 +45,7 @@ RT_DEV float power_heuristic(float fPdf, float gPdf) {
 // single-precision polynomials instead (Cephes-style: Cody-Waite reduction, minimax polynomials), every step one
 // IEEE operation, so that a CPU restatement of the same steps yields the same bits and films can be compared
 // exactly.  Accuracy against the exact functions: sin/cos 1.5 ulp (absolute 8e-8 near their zeros), acos 1.3 ulp,
-// atan2 3.1 ulp, log2 1.7 ulp.
+// atan2 3.1 ulp, log2 1.7 ulp; log and exp (the microfacet lobe) 1 ulp class, pow = exp(y log x).
 // sine and cosine of |x| < 1e4 (this path's arguments lie in [-pi/4, 2 pi]); NaN otherwise
 RT_DEV void dm_sincos(float x, float& s, float& c) {
     const float ax = fabsf(x);
@@ -98,6 +98,42 @@ RT_DEV float dm_log2(float x) {             // positive normal x; +inf gives 128
     y = y - 0.5f * z;
     return (float)e + (f + y) * 1.44269504088896341f;
 }
+
+// natural logarithm of x >= 0 (zero gives -inf, denormals are scaled up first); NaN for negative x and NaN
+RT_DEV float dm_log(float x) {
+    if (!(x >= 0.0f)) return __uint_as_float(0x7FC00000u);
+    if (x == 0.0f) return -__builtin_inff();
+    if (!(x < __builtin_inff())) return x;
+    int e = 0;
+    if (x < 1.17549435e-38f) { x = x * 8388608.0f; e = -23; }
+    const uint32_t b = __float_as_uint(x);
+    e += (int)(b >> 23) - 127;
+    float m = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);   // [1, 2)
+    if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+    const float f = m - 1.0f, z = f * f, fe = (float)e;
+    float y = ((((((((7.0376836292e-2f * f - 1.1514610310e-1f) * f + 1.1676998740e-1f) * f - 1.2420140846e-1f) * f + 1.4249322787e-1f) * f -
+                  1.6668057665e-1f) * f + 2.0000714765e-1f) * f - 2.4999993993e-1f) * f + 3.3333331174e-1f) * f * z;
+    y = y + -2.12194440e-4f * fe;
+    y = y - 0.5f * z;
+    return (f + y) + 0.693359375f * fe;
+}
+RT_DEV float dm_pow2i(int k) { return __uint_as_float((uint32_t)(k + 127) << 23); }   // 2^k, k in [-126, 127]
+// e^x: +inf above 88.72, 0 below -103.9 (-inf included); NaN for NaN
+RT_DEV float dm_exp(float x) {
+    if (x != x) return x;
+    if (x > 88.72283905206835f) return __builtin_inff();
+    if (x < -103.9f) return 0.0f;
+    const float n = floorf(1.44269504088896341f * x + 0.5f);
+    x = x - n * 0.693359375f;
+    x = x - n * -2.12194440e-4f;
+    const float z = x * x;
+    const float p = (((((1.9875691500e-4f * x + 1.3981999507e-3f) * x + 8.3334519073e-3f) * x + 4.1665795894e-2f) * x + 1.6666665459e-1f) * x +
+                     5.0000001201e-1f) * z + x + 1.0f;
+    const int k = (int)n, k1 = k / 2;
+    return p * dm_pow2i(k1) * dm_pow2i(k - k1);
+}
+// x^y for x >= 0 as exp(y log x) (the lobe raises a number of (0, 1] to a power near 1)
+RT_DEV float dm_pow(float x, float y) { return dm_exp(y * dm_log(x)); }
 
 // Counter-based sampler: one draw is a pure function of (seed, pixel, pass,
 // dimension).  Stands in for the per-tile std::mt19937(std::random_device())

@@ -238,7 +238,7 @@ RT_DEV float sin2_phi(f3 w) { return sin_phi(w) * sin_phi(w); }
 RT_DEV float erf_inv(float x) {
     float w, p;
     x = clampf(x, -.99999f, .99999f);
-    w = -logf((1 - x) * (1 + x));
+    w = -dm_log((1 - x) * (1 + x));
     if (w < 5) {
         w = w - 2.5f;
         p = 2.81022636e-08f;
@@ -272,14 +272,14 @@ RT_DEV float erf_poly(float x) {
     if (x < 0) sign = -1;
     x = fabsf(x);
     float t = 1 / (1 + p * x);
-    float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * expf(-x * x);
+    float y = 1 - (((((a5 * t + a4) * t) + a3) * t + a2) * t + a1) * t * dm_exp(-x * x);
     return sign * y;
 }
 
 // src/bsdf/Microfacet.cpp:7-80
 RT_DEV void beckmann_sample11(float cosThetaI, float U1, float U2, float& slope_x, float& slope_y) {
     if ((double)cosThetaI > .9999) {
-        float r = sqrtf(-logf(1.0f - U1));
+        float r = sqrtf(-dm_log(1.0f - U1));
         float sinPhi = dm_sin(2 * kPi * U2);
         float cosPhi = dm_cos(2 * kPi * U2);
         slope_x = r * cosPhi;
@@ -293,14 +293,14 @@ RT_DEV void beckmann_sample11(float cosThetaI, float U1, float U2, float& slope_
     float sample_x = gmax(U1, 1e-6f);
     float thetaI = dm_acos(cosThetaI);
     float fit = 1 + thetaI * (-0.876f + thetaI * (0.4265f - 0.0594f * thetaI));
-    float b = c - (1 + c) * powf(1 - sample_x, fit);
+    float b = c - (1 + c) * dm_pow(1 - sample_x, fit);
     const float SQRT_PI_INV = 1.f / sqrtf(kPi);
-    float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * expf(-cotThetaI * cotThetaI));
+    float normalization = 1 / (1 + c + SQRT_PI_INV * tanThetaI * dm_exp(-cotThetaI * cotThetaI));
     int it = 0;
     while (++it < 10) {
         if (!(b >= a && b <= c)) b = 0.5f * (a + c);
         float invErf = erf_inv(b);
-        float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * expf(-invErf * invErf)) - sample_x;
+        float value = normalization * (1 + b + SQRT_PI_INV * tanThetaI * dm_exp(-invErf * invErf)) - sample_x;
         float derivative = normalization * (1 - invErf * tanThetaI);
         if (fabsf(value) < 1e-5f) break;
         if (value > 0)
@@ -355,7 +355,7 @@ RT_DEV float mf_D(const MicrofacetK& m, f3 wh) {
     if (isinf(t2)) return 0.f;
     float cos4Theta = cos2_theta(wh) * cos2_theta(wh);
     if (m.kind == RT_GLOSSY_BECKMANN_K)
-        return expf(-t2 * (cos2_phi(wh) / (m.ax * m.ax) + sin2_phi(wh) / (m.ay * m.ay))) / (kPi * m.ax * m.ay * cos4Theta);
+        return dm_exp(-t2 * (cos2_phi(wh) / (m.ax * m.ax) + sin2_phi(wh) / (m.ay * m.ay))) / (kPi * m.ax * m.ay * cos4Theta);
     float e = (cos2_phi(wh) / (m.ax * m.ax) + sin2_phi(wh) / (m.ay * m.ay)) * t2;
     return 1 / (kPi * m.ax * m.ay * cos4Theta * (1 + e) * (1 + e));
 }

@@ -1,8 +1,7 @@
 """Films bit for bit.  With the oracle's transcendentals switched to the fixed polynomials the kernels restate
-(oracle.binding.set_math("shared")), nothing on the reference path (Oren-Nayar BSDF, point / environment lights,
-textures) differs between the two sides any more, so the film of the HIP tracer must equal the oracle's exactly,
-NaN for NaN.  (The distance between the shared-math and the libm oracle is bounded in test_oracle_math.py; the
-glossy lobe still calls exp / log / pow and keeps its tolerance.)"""
+(oracle.binding.set_math("shared")), nothing (Oren-Nayar BSDF, point / environment / area lights, textures, the microfacet
+lobes) differs between the two sides any more, so the film of the HIP tracer must equal the oracle's exactly,
+NaN for NaN.  (The distance between the shared-math and the libm oracle is bounded in test_oracle_math.py.)"""
 import numpy as np
 import pytest
 
@@ -57,12 +56,13 @@ def test_many_lights(cornell):
     _exact(scenes.replace(cornell, lights=lights), 96, 96, 4, 9, 2)
 
 
-def test_ggx_lobe_and_area_lights(atrium_small):
-    # the GGX lobe needs no exp / log / pow, so it is exact as well (the Beckmann lobe keeps its tolerance,
-    # tests/test_gpu_glossy_area.py)
+@pytest.mark.parametrize("kind", [scenes.GLOSSY_GGX, scenes.GLOSSY_BECKMANN])
+def test_microfacet_lobes_and_area_lights(atrium_small, kind):
+    # the Beckmann lobe's exp / log / pow are shared polynomials too
     panel = scenes.area_quad((-6, 14.5, -3), (6, 14.5, -3), (6, 14.5, 3), (-6, 14.5, 3), (60.0, 55.0, 45.0))
-    s = scenes.with_glossy(scenes.replace(atrium_small, lights=atrium_small.lights + panel), scenes.GLOSSY_GGX)
+    s = scenes.with_glossy(scenes.replace(atrium_small, lights=atrium_small.lights + panel), kind)
     _exact(s, 120, 68, 6, 4, 2)
+    _exact(scenes.cornell_area(glossy=kind), 48, 48, 4, 2, 3)
 
 
 def test_ragged_film_and_odd_tiles(cornell_env):

@@ -36,6 +36,24 @@ def test_acos_atan2_log2_accuracy():
     assert np.abs(ob.dm_eval("log2", r) - np.log2(r.astype(np.float64))).max() < 2e-6
 
 
+def test_log_exp_pow_accuracy():
+    rng = np.random.default_rng(1)
+    x = np.exp(rng.uniform(-80, 80, 500_000)).astype(np.float32)
+    assert _ulps(ob.dm_eval("log", x), np.log(x.astype(np.float64))).max() < 1.0
+    x = rng.uniform(-85, 88, 500_000).astype(np.float32)
+    assert _ulps(ob.dm_eval("exp", x), np.exp(x.astype(np.float64))).max() < 1.5
+    x, y = rng.uniform(1e-6, 1, 500_000).astype(np.float32), rng.uniform(0.5, 2, 500_000).astype(np.float32)
+    ref = np.power(x.astype(np.float64), y.astype(np.float64))
+    assert (np.abs(ob.dm_eval("pow", x, y) - ref) / ref).max() < 4e-6
+    f = lambda *v: np.asarray(v, np.float32)
+    out = ob.dm_eval("log", f(0, 1, -1, np.inf, np.nan, 1e-40))
+    assert out[0] == -np.inf and out[1] == 0 and np.isnan(out[2]) and out[3] == np.inf and np.isnan(out[4])
+    assert abs(out[5] - np.log(1e-40)) < 1e-4                                     # denormal argument
+    out = ob.dm_eval("exp", f(0, -np.inf, np.inf, np.nan, -104, 89))
+    assert out[0] == 1 and out[1] == 0 and out[2] == np.inf and np.isnan(out[3]) and out[4] == 0 and out[5] == np.inf
+    assert ob.dm_eval("exp", f(-100))[0] > 0                                       # denormal result, two-step scaling
+
+
 def test_edge_cases():
     f = lambda *v: np.asarray(v, np.float32)
     pi = np.float32(np.pi)
