@@ -342,9 +342,11 @@ def sponza_class(detail: float = 1.1, env_size=(2048, 1024)) -> Scene:
     return b.finish(lights, cam, f"sponza_class(detail={detail})", jitter=2e-4, seed=1)
 
 
-def bistro_class(blocks=(4, 3), detail: float = 1.1, n_point_lights: int = 64, env_size=(1024, 512)) -> Scene:
+def bistro_class(blocks=(4, 3), detail: float = 1.1, n_point_lights: int = 64, env_size=(1024, 512), area_lights: bool = False) -> Scene:
     """A street block of atria: >= 2.8 M triangles at blocks=(4,3), many point
-    lights (the reference has no area lights)."""
+    lights (the reference has no area lights).  area_lights=True puts a small
+    downward-facing emissive triangle in place of each point light (the
+    build's own light kind, behind the same sampleLi / pdfLi / le interface)."""
     b = _Builder()
     k = 0
     for bx in range(blocks[0]):
@@ -355,10 +357,15 @@ def bistro_class(blocks=(4, 3), detail: float = 1.1, n_point_lights: int = 64, e
     lights = []
     for i in range(n_point_lights):
         p = np.array([rng.uniform(-15, blocks[0] * 40 - 25), rng.uniform(3, 12), rng.uniform(-9, blocks[1] * 26 - 17)], np.float32)
-        lights.append(Light(LIGHT_POINT, p, np.full(3, 30.0, np.float32)))
+        if area_lights:
+            # a 0.6 m triangle facing down (normal = cross(p1 - p0, p2 - p0) = -y), about the point light's power
+            tri = np.stack([p + np.array(d, np.float32) for d in ((-0.3, 0.0, -0.2), (0.3, 0.0, -0.2), (0.0, 0.0, 0.4))])
+            lights.append(Light(LIGHT_AREA, intensity=np.full(3, 160.0, np.float32), tri=tri))
+        else:
+            lights.append(Light(LIGHT_POINT, p, np.full(3, 30.0, np.float32)))
     lights.append(Light(LIGHT_ENV, intensity=np.array([5.0, 5.0, 5.0], np.float32), env=sky_env(*env_size)))
     cam = make_camera((-16.5, 3.2, 1.3), (1.0, 0.05, 0.35))
-    return b.finish(lights, cam, f"bistro_class(blocks={blocks},detail={detail})", jitter=2e-4, seed=2)
+    return b.finish(lights, cam, f"bistro_class(blocks={blocks},detail={detail},area_lights={area_lights})", jitter=2e-4, seed=2)
 
 
 # --------------------------------------------------------------- textures

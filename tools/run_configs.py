@@ -100,6 +100,18 @@ def main():
                                                "cpu_oracle_240x136_1spp": c, "agreement_240x136": agree(fs, rs),
                                                "finite": bool(np.isfinite(film).all())}
         print("c5", json.dumps(out["c5_bistro_1080p_d12_65lights"]), flush=True)
+    if "c5a" in which:
+        # C5 as worded in BASELINE.json ("many area lights"): the same street block with an emissive triangle in
+        # place of each point light (bounded shadow rays, the build's own light kind)
+        b = scenes.bistro_class(area_lights=True)
+        film, g = gpu_render(b, 1920, 1080, 12, 4)
+        g["extrapolated_seconds_256spp"] = g["seconds"] * 64
+        fs, gs = gpu_render(b, 240, 136, 12, 1, seed=4)
+        rs, c = cpu_render(b, 240, 136, 12, 1, seed=4)
+        out["c5a_bistro_1080p_d12_64_area_lights"] = {"n_lights": len(b.lights), "gpu_4spp": g, "cpu_oracle_240x136_1spp": c,
+                                                      "agreement_240x136": agree(fs, rs), "finite": bool(np.isfinite(film).all()),
+                                                      "mean_rgb": film[..., :3].mean((0, 1)).tolist()}
+        print("c5a", json.dumps(out["c5a_bistro_1080p_d12_64_area_lights"]), flush=True)
     if "tex" in which:
         # C3's scene with diffuse maps on every model: cost of k_quad_duv + the filtered fetches
         sp = scenes.sponza_class()
