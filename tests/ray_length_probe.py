@@ -1,6 +1,6 @@
-"""Development probe (CPU only): distribution of the traversal length (inner visits + triangle tests) of the rays of
+"""Development probe (CPU only; under tests/ because it runs the oracle): distribution of the traversal length (inner visits + triangle tests) of the rays of
 the C2 sets, from the oracle.  The longest rays set the length of a launch's drain.
-usage: python tools/ray_length_probe.py [stride]"""
+usage: python tests/ray_length_probe.py [stride]"""
 import ctypes as C
 import os
 import sys

@@ -1,7 +1,8 @@
-"""Runs the BASELINE.json configurations that fit one GPU and writes
+"""Measurement script (kept under tests/ because it runs the CPU oracle as checker and baseline; pytest does not
+collect it).  Runs the BASELINE.json configurations that fit one GPU and writes
 profiles/<tag>/configs.json: GPU time, CPU-oracle time on a bounded sample,
 and film agreement where both sides render the same passes.
-usage (on the GPU box): python tools/run_configs.py <out.json> [c1 c3 c4 c5]"""
+usage (on the GPU box): python tests/run_configs.py <out.json> [c1 c3 c4 c5]"""
 import json
 import os
 import sys
