@@ -137,7 +137,9 @@ typedef struct rt_stats {
 
 /* Replaces Integrator::Integrator (src/cpu/Integrator.cpp:7-15): builds the
  * LBVH of src/scene/BVH.cpp:287-336 (on the GPU by default), uploads scene
- * and film. */
+ * and film.  RT_ERR_LIMIT when the node or triangle array would reach 4 GiB
+ * (about 33 M triangles: the traversal kernels address them with 32-bit byte
+ * offsets). */
 int rt_create(const rt_scene_desc* scene, const rt_params* params, rt_ctx** out);
 void rt_destroy(rt_ctx* ctx);
 /* Error text of the last failed call on ctx (ctx may be null for rt_create). */
