@@ -112,7 +112,8 @@ typedef struct rt_params {
     int32_t rank, world;   /* world 0 or 1 -> whole film */
     uint32_t flags;        /* rt_flags; 0 = defaults */
     uint32_t batch;        /* passes rt_render traces together as one wavefront (more rays per launch;
-                              path state grows with it); 0 -> 16, limited by a 48 GiB budget.  The film is
+                              path state grows with it: 144 B per pixel slot, 16 B more in textured scenes, and
+                              41 B per slot and light, 45 B with area lights); 0 -> 16, limited by a 48 GiB budget.  The film is
                               the one that many separate passes leave, bit for bit. */
 } rt_params;
 
@@ -133,13 +134,18 @@ typedef struct rt_stats {
     float bvh_build_ms;        /* LBVH build (GPU or host) including its uploads, wall */
     uint64_t exact_closest_rays; /* of closest_rays / shadow_rays: rays whose operands the fast box test cannot */
     uint64_t exact_shadow_rays;  /* decide like the reference's selects, re-traced by the exact follow-up launch */
+    uint64_t device_bytes;       /* device memory the context holds (scene, tables, path state, staging) */
+    uint64_t path_state_bytes;   /* of that: path state, shadow entries and film, the part that grows with batch */
+    uint32_t batch;              /* passes rt_render traces together (rt_params.batch after the budget) */
 } rt_stats;
 
 /* Replaces Integrator::Integrator (src/cpu/Integrator.cpp:7-15): builds the
  * LBVH of src/scene/BVH.cpp:287-336 (on the GPU by default), uploads scene
- * and film.  RT_ERR_LIMIT when the node or triangle array would reach 4 GiB
- * (about 33 M triangles: the traversal kernels address them with 32-bit byte
- * offsets). */
+ * and film.  RT_ERR_LIMIT when the node array (64 B per node slot, about one
+ * slot per triangle) or the triangle array (48 B each) would reach 4 GiB,
+ * i.e. from about 67 M triangles: the traversal kernels address both with
+ * unsigned 32-bit byte offsets.  Also when max_depth * (4 * n_lights + 2)
+ * exceeds the sampler's 65536 dimensions. */
 int rt_create(const rt_scene_desc* scene, const rt_params* params, rt_ctx** out);
 void rt_destroy(rt_ctx* ctx);
 /* Error text of the last failed call on ctx (ctx may be null for rt_create). */

@@ -66,7 +66,8 @@ class rt_stats(C.Structure):
     _fields_ = [("closest_rays", C.c_uint64), ("shadow_rays", C.c_uint64), ("passes", C.c_uint64),
                 ("n_nodes", C.c_uint32), ("n_triangles", C.c_uint32), ("bvh_max_depth", C.c_int32),
                 ("n_local_pixels", C.c_uint32), ("last_trace_ms", C.c_float), ("last_render_ms", C.c_float),
-                ("bvh_build_ms", C.c_float), ("exact_closest_rays", C.c_uint64), ("exact_shadow_rays", C.c_uint64)]
+                ("bvh_build_ms", C.c_float), ("exact_closest_rays", C.c_uint64), ("exact_shadow_rays", C.c_uint64),
+                ("device_bytes", C.c_uint64), ("path_state_bytes", C.c_uint64), ("batch", C.c_uint32)]
 
 
 EXPORTS = [

@@ -145,7 +145,11 @@ RT_DEV uint64_t splitmix64(uint64_t z) {
     return z ^ (z >> 31);
 }
 RT_DEV float rng_u01(uint64_t seed_mixed, uint32_t pixel, uint32_t pass, uint32_t dim) {
-    uint64_t ctr = ((uint64_t)pass << 48) ^ ((uint64_t)pixel << 16) ^ (uint64_t)dim;
+    // 16 bits each for the dimension and the low half of the pass number, 32 for the pixel; the high half of the
+    // pass number re-keys the stream, so accumulation can run past 65535 passes without repeating a sequence
+    const uint32_t pass_hi = pass >> 16;
+    if (pass_hi) seed_mixed = splitmix64(seed_mixed ^ ((uint64_t)pass_hi << 32));
+    uint64_t ctr = ((uint64_t)(pass & 0xFFFFu) << 48) ^ ((uint64_t)pixel << 16) ^ (uint64_t)dim;
     uint64_t z = splitmix64(seed_mixed ^ ctr);
     return (float)(z >> 40) * 0x1p-24f;
 }

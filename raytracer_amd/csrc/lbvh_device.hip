@@ -239,8 +239,18 @@ int build_lbvh_device(const float* d_pos, const uint32_t* d_idx, uint32_t n_indi
     out->n_tris = T;
     out->n_ref_nodes = (uint32_t)NN;
     out->n_node_slots = T > 1 ? top_slots + (T - 1) : 0;
-    std::vector<void*> tmp;  // scratch freed before returning
-    auto free_tmp = [&]() { for (void* p : tmp) (void)hipFree(p); tmp.clear(); };
+    // scratch freed on every way out (the error returns of LB_TRY included)
+    struct Scratch : std::vector<void*> {
+        hipStream_t stream;
+        explicit Scratch(hipStream_t s) : stream(s) {}
+        void release() {
+            if (!empty()) (void)hipStreamSynchronize(stream);
+            for (void* p : *this) (void)hipFree(p);
+            clear();
+        }
+        ~Scratch() { release(); }
+    } tmp(stream);
+    auto free_tmp = [&]() { tmp.release(); };
 
     float *pmin, *pmax, *cen;
     uint32_t *bounds, *codes, *ids, *codes_s, *ids_s, *counter;

@@ -2,6 +2,7 @@
 // context, scene upload, the per-pass wavefront schedule, film read-back.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -72,6 +73,9 @@ struct rt_ctx {
 
     // path state
     std::vector<void*> allocs;
+    std::vector<size_t> alloc_sizes;
+    uint64_t device_bytes = 0;       // everything dev_alloc holds
+    uint64_t path_state_bytes = 0;   // of that, what grows with slots x batch (path state and shadow entries)
     PathBuffers pb{};
     uint32_t* d_q0 = nullptr;
     // path state of the current / next bounce (rays, beta, slot ids), swapped after every bounce
@@ -134,8 +138,23 @@ int dev_alloc(rt_ctx* c, T** p, size_t count) {
         return RT_ERR_HIP;
     }
     c->allocs.push_back(q);
+    c->alloc_sizes.push_back(bytes);
+    c->device_bytes += bytes;
     *p = static_cast<T*>(q);
     return RT_OK;
+}
+
+// Frees one dev_alloc'ed buffer early (grow-only staging that has been outgrown).
+void dev_release(rt_ctx* c, void* p) {
+    if (!p) return;
+    for (size_t i = 0; i < c->allocs.size(); ++i)
+        if (c->allocs[i] == p) {
+            (void)hipFree(p);
+            c->device_bytes -= c->alloc_sizes[i];
+            c->allocs.erase(c->allocs.begin() + (long)i);
+            c->alloc_sizes.erase(c->alloc_sizes.begin() + (long)i);
+            return;
+        }
 }
 
 template <typename T>
@@ -224,8 +243,12 @@ uint32_t grid_for(const rt_ctx* c, uint32_t n) {
 
 int ensure_trace_staging(rt_ctx* c, uint32_t n) {
     if (n <= c->tr_cap) return RT_OK;
-    // grow-only staging for the host-pointer entry points
+    // grow-only staging for the host-pointer entry points; the outgrown pair is idle here (every entry point that
+    // uses it waits for its copies before it returns)
     int r;
+    dev_release(c, c->d_tr_rays); c->d_tr_rays = nullptr;
+    dev_release(c, c->d_tr_out); c->d_tr_out = nullptr;
+    c->tr_cap = 0;
     if ((r = dev_alloc(c, &c->d_tr_rays, (size_t)n * 6))) return r;
     if ((r = dev_alloc(c, &c->d_tr_out, (size_t)n * 5))) return r;
     c->tr_cap = n;
@@ -235,6 +258,9 @@ int ensure_trace_staging(rt_ctx* c, uint32_t n) {
 // The deferred list of the rt_trace_* launches must be able to hold every ray.
 int ensure_deferred(rt_ctx* c, uint32_t n) {
     if (n <= c->deferred_cap) return RT_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));   // an earlier launch may still append to the old list
+    dev_release(c, c->d_deferred); c->d_deferred = nullptr;
+    c->deferred_cap = 0;
     int r = dev_alloc(c, &c->d_deferred, n);
     if (r) return r;
     c->deferred_cap = n;
@@ -368,7 +394,9 @@ int run_pass(rt_ctx* c, uint32_t nb) {
         }
     }
     c->last_buf = cur;
-    hipLaunchKernelGGL(k_film, dim3((c->n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->pb, (float)c->frames, nb);
+    // the reference counts passes in a float (src/cpu/Integrator.hpp:50, `_frames++`), which stops growing at 2^24
+    const float frames_f = (float)std::min<uint64_t>(c->frames, 1ull << 24);
+    hipLaunchKernelGGL(k_film, dim3((c->n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->pb, frames_f, nb);
     HIP_TRY(c, hipGetLastError());
     c->frames += nb;
     return RT_OK;
@@ -410,6 +438,11 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     if (pr->width <= 0 || pr->height <= 0 || pr->max_depth <= 0 || pr->max_depth > 64) {
         c->err = "width, height must be positive and max_depth in 1..64";
         return RT_ERR_ARG;
+    }
+    // the sampler gives the dimension d * (4 L + 2) + 4 l + k sixteen bits
+    if ((uint64_t)pr->max_depth * (4ull * sd->n_lights + 2ull) > 0x10000ull) {
+        c->err = "max_depth * (4 * n_lights + 2) exceeds 65536 sampler dimensions";
+        return RT_ERR_LIMIT;
     }
     if ((uint64_t)pr->width * (uint64_t)pr->height >= 0xFFFFFFFFull) {
         c->err = "film too large";
@@ -500,18 +533,22 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
             const float* q = strided(sd->pos, pstride, v);
             packed[3 * (size_t)v] = q[0]; packed[3 * (size_t)v + 1] = q[1]; packed[3 * (size_t)v + 2] = q[2];
         }
-        float* d_pos = nullptr;
-        uint32_t* d_idx = nullptr;
-        int32_t* d_tm = nullptr;
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_pos), packed.size() * sizeof(float)));
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_idx), (size_t)sd->n_indices * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&d_tm), (size_t)T * sizeof(int32_t)));
+        // build inputs live only for the build: freed on every way out
+        struct Scratch {
+            void* p[3] = {nullptr, nullptr, nullptr};
+            ~Scratch() { for (void* q : p) if (q) (void)hipFree(q); }
+        } tmp;
+        HIP_TRY(c, hipMalloc(&tmp.p[0], packed.size() * sizeof(float)));
+        HIP_TRY(c, hipMalloc(&tmp.p[1], (size_t)sd->n_indices * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&tmp.p[2], (size_t)T * sizeof(int32_t)));
+        float* d_pos = static_cast<float*>(tmp.p[0]);
+        uint32_t* d_idx = static_cast<uint32_t*>(tmp.p[1]);
+        int32_t* d_tm = static_cast<int32_t*>(tmp.p[2]);
         HIP_TRY(c, hipMemcpy(d_pos, packed.data(), packed.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(d_idx, sd->indices, (size_t)sd->n_indices * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(c, hipMemcpy(d_tm, sd->tri_model, (size_t)T * sizeof(int32_t), hipMemcpyHostToDevice));
         std::string berr;
         int br = build_lbvh_device(d_pos, d_idx, sd->n_indices, d_tm, RT_TOP_LEVELS, c->stream, &c->dbvh, &berr);
-        (void)hipFree(d_pos); (void)hipFree(d_idx); (void)hipFree(d_tm);
         if (br != 0) {
             c->err = "GPU LBVH build: " + berr;
             return RT_ERR_HIP;
@@ -714,7 +751,10 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     // path-state budget of 48 GiB and 32-bit entry indices
     {
         const uint64_t L1 = (uint64_t)std::max<uint32_t>(1, sd->n_lights);
-        const uint64_t per_slot = 170 + 45 * L1;   // bytes of path state and shadow entries per slot
+        // bytes of path state per slot (rays, beta and slot ids twice; hit; L; vertex; status; pixel id; queue entry;
+        // deferred list; UV differences in textured scenes) and of shadow entries per slot and light (direction,
+        // contributions, state, deferred list, far bound with area lights)
+        const uint64_t per_slot = 144 + (sd->n_textures ? 16 : 0) + (41 + (c->any_area ? 4 : 0)) * L1;
         uint64_t S = pr->batch ? pr->batch : 16;
         const uint64_t one = std::max<uint64_t>(1, (uint64_t)c->n_slots);
         S = std::min<uint64_t>(S, std::max<uint64_t>(1, (48ull << 30) / (per_slot * one)));
@@ -724,6 +764,7 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         c->n_total = c->batch * c->n_slots;
     }
     const size_t n = c->n_total;
+    const uint64_t bytes_before_state = c->device_bytes;
     {
         std::vector<uint32_t> sp(n ? n : 1, 0xFFFFFFFFu), qa;
         qa.reserve((size_t)c->batch * q0.size());
@@ -776,18 +817,17 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
             c->err = "lights x pixels exceeds the shadow queue limit";
             return RT_ERR_LIMIT;
         }
-        for (int p = 0; p < 2; ++p) {
-            ShadowQueue& q = c->sq;
-            q.cap = (uint32_t)cap;
-            if ((r = dev_alloc(c, &q.dir, 3 * cap))) return r;
-            q.tmax = nullptr;
-            if (c->any_area && (r = dev_alloc(c, &q.tmax, cap))) return r;
-            if ((r = dev_alloc(c, &q.contrib, 6 * cap))) return r;
-            if ((r = dev_alloc(c, &q.state, cap))) return r;
-        }
+        ShadowQueue& q = c->sq;
+        q.cap = (uint32_t)cap;
+        if ((r = dev_alloc(c, &q.dir, 3 * cap))) return r;
+        q.tmax = nullptr;
+        if (c->any_area && (r = dev_alloc(c, &q.tmax, cap))) return r;
+        if ((r = dev_alloc(c, &q.contrib, 6 * cap))) return r;
+        if ((r = dev_alloc(c, &q.state, cap))) return r;
         // the exact follow-up launch of a bounce can defer up to every shadow entry and every path
         if ((r = dev_alloc(c, &c->d_pass_deferred_b, cap + n))) return r;
     }
+    c->path_state_bytes = c->device_bytes - bytes_before_state;
     if ((r = dev_alloc(c, &c->d_work, 1))) return r;
     if ((r = dev_alloc(c, &c->d_raystats, 4))) return r;
     HIP_TRY(c, hipMemset(c->d_raystats, 0, 4 * sizeof(unsigned long long)));
@@ -837,8 +877,8 @@ int rt_render(rt_ctx* c, uint32_t n_passes) {
         c->err = "rt_render: no camera set";
         return RT_ERR_STATE;
     }
-    if (c->frames + n_passes > 0xFFFFull) {
-        c->err = "rt_render: more than 65535 accumulated passes";
+    if (c->frames + n_passes > 0xFFFFFFFFull) {   // the sampler keys a draw by a 32-bit pass number
+        c->err = "rt_render: more than 2^32 - 1 accumulated passes";
         return RT_ERR_LIMIT;
     }
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1136,6 +1176,9 @@ int rt_get_stats(rt_ctx* c, rt_stats* out) {
     out->last_trace_ms = c->last_trace_ms;
     out->last_render_ms = c->last_render_ms;
     out->bvh_build_ms = c->bvh_build_ms;
+    out->device_bytes = c->device_bytes;
+    out->path_state_bytes = c->path_state_bytes;
+    out->batch = c->batch;
     return RT_OK;
 }
 

@@ -237,8 +237,8 @@ struct TraceWork {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // 16 bytes at byte offset `off` of a buffer resource
-RT_DEV float4 ldb128(__amdgpu_buffer_rsrc_t rs, int off) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+RT_DEV float4 ldb128(__amdgpu_buffer_rsrc_t rs, uint32_t off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 #ifdef RT_PROBE
@@ -382,9 +382,9 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                                      "+v"(c.z), "+v"(c.w), "+v"(left), "+v"(right));
                     } else {
                         // through a buffer resource: one 32-bit offset instead of a 64-bit address per lane
-                        const int off = cur << 6;
+                        const uint32_t off = (uint32_t)cur << 6;   // < 4 GiB: checked by the host
                         a = ldb128(rs_nodes, off); b = ldb128(rs_nodes, off + 16); c = ldb128(rs_nodes, off + 32);
-                        const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rs_nodes, off + 48, 0, 0);   // the other 8 bytes are padding
+                        const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rs_nodes, (int)(off + 48u), 0, 0);   // the other 8 bytes are padding
                         left = (int32_t)d.x; right = (int32_t)d.y;
                     }
                     float ld, rdist;
@@ -423,7 +423,7 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
         if (n_leaf >= leaf_min || (n_leaf > 0 && __ballot(cur >= 0) == 0ull)) {
             RT_PROBE_ADD(4, 1); RT_PROBE_ADD(5, n_leaf);
             if (at_leaf) {
-                const int toff = (~cur) * 48;
+                const uint32_t toff = (uint32_t)(~cur) * 48u;   // < 4 GiB: checked by the host
                 float4 a = ldb128(rs_tris, toff), b = ldb128(rs_tris, toff + 16), c = ldb128(rs_tris, toff + 32);
                 float t, u, v;
                 bool finished = false;

@@ -27,21 +27,39 @@ def gather_slabs(local_slab: torch.Tensor, width: int, height: int, tile_size: i
     return unpack_slabs(width, height, tile_size, world, gathered.cpu().numpy(), per_rank)
 
 
+def _buffers(ctx: Context, world: int, per_rank: int, dev: torch.device):
+    """The three device buffers of a read-out (own slab, gathered slabs, film), kept on the context between calls."""
+    key = (world, per_rank, dev)
+    cache = getattr(ctx, "_gather_buffers", None)
+    if cache is None or cache[0] != key:
+        local = torch.zeros(per_rank, dtype=torch.float32, device=dev)   # the padding behind the slab stays zero
+        gathered = torch.empty(world * per_rank, dtype=torch.float32, device=dev)
+        film = torch.empty((ctx.height, ctx.width, 4), dtype=torch.float32, device=dev)
+        cache = (key, local, gathered, film)
+        ctx._gather_buffers = cache
+    return cache[1:]
+
+
 def gather_film_device(ctx: Context, group=None) -> torch.Tensor:
     """Gathers the tile-sharded film of a multi-rank render and assembles it on the device: every rank ends up with
-    the (H, W, 4) film as a CUDA tensor.  One all-gather of the padded slabs, one scatter kernel, no host copy."""
+    the (H, W, 4) film as a CUDA tensor (owned by the context and overwritten by the next call).  One all-gather of
+    the padded slabs, one scatter kernel, no host copy.
+
+    The library works on a stream of its own that has no implicit ordering with torch's streams, so every hand-over
+    between the two is an explicit wait: torch's stream is drained before the library writes into a torch buffer,
+    and the library calls return only when their work is done (rt_copy_film_slab, rt_unpack_slabs_dev)."""
     world = dist.get_world_size(group)
     _, _, n_floats = ctx.film_slab_info()
     dev = torch.device("cuda", torch.cuda.current_device())
     per_rank = max(slab_floats(ctx.width, ctx.height, ctx.tile_size, r, world) for r in range(world))
-    local = torch.zeros(per_rank, dtype=torch.float32, device=dev)
+    local, gathered, film = _buffers(ctx, world, per_rank, dev)
+    stream = torch.cuda.current_stream(dev)
+    stream.synchronize()          # the fill of `local` and earlier readers of the buffers are done
     if n_floats:
-        ctx.copy_film_slab(local.data_ptr(), n_floats)
-    gathered = torch.empty(world * per_rank, dtype=torch.float32, device=dev)
+        ctx.copy_film_slab(local.data_ptr(), n_floats)   # returns after the copy
     dist.all_gather_into_tensor(gathered, local, group=group)
-    torch.cuda.synchronize(dev)   # the library's stream is not torch's
-    film = torch.empty((ctx.height, ctx.width, 4), dtype=torch.float32, device=dev)
-    ctx.unpack_slabs_dev(world, gathered.data_ptr(), per_rank, film.data_ptr())
+    stream.synchronize()          # the gather is done before the library's stream reads it
+    ctx.unpack_slabs_dev(world, gathered.data_ptr(), per_rank, film.data_ptr())   # returns after the scatter
     return film
 
 

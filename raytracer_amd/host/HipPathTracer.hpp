@@ -42,14 +42,15 @@ class HipPathTracer {
     }
     ~HipPathTracer() {
         finish();
-        if (_renderThread && _renderThread->joinable()) _renderThread->join();
         rt_destroy(_ctx);
     }
     HipPathTracer(const HipPathTracer&) = delete;
     HipPathTracer& operator=(const HipPathTracer&) = delete;
 
-    // src/cpu/Integrator.cpp:69-79: the render loop; one library pass per update()
+    // src/cpu/Integrator.cpp:69-79: the render loop; one library pass per update().  The thread leaves
+    // _isFinish set whichever way it ends, so a host that polls isUpdateFinish() never waits on a dead thread.
     void run() {
+        if (_renderThread) return;
         _renderThread = std::make_shared<std::thread>([this]() {
             while (_isRun) {
                 if (!_isFinish) {
@@ -59,23 +60,32 @@ class HipPathTracer {
                     std::this_thread::yield();
                 }
             }
+            _isFinish = true;
         });
     }
     bool isUpdateFinish() const { return _isFinish; }  // src/cpu/Integrator.cpp:81-83
 
-    // src/cpu/Integrator.cpp:85-92: snapshot the camera; up = normalize(cross(right, forward))
+    // src/cpu/Integrator.cpp:85-92: snapshot the camera; up = normalize(cross(right, forward)).  Does nothing once the
+    // library has reported an error (see error()) or after finish(): there is no thread left to pick the frame up.
     void nextFrame(const float pos[3], const float right[3], const float forward[3]) {
+        if (_failed || !_isRun) return;
         float c[3] = {right[1] * forward[2] - forward[1] * right[2], right[2] * forward[0] - forward[2] * right[0],
                       right[0] * forward[1] - forward[0] * right[1]};
         float inv = 1.0f / std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
         for (int i = 0; i < 3; ++i) { _pos[i] = pos[i]; _right[i] = right[i]; _forward[i] = forward[i]; _up[i] = c[i] * inv; }
         _isFinish = false;
     }
-    // src/cpu/Integrator.cpp:94-97
+    // src/cpu/Integrator.cpp:94-97: stops the loop and joins the thread (the reference spins on _isFinish, which a
+    // thread that has already left its loop would never set)
     void finish() {
         _isRun = false;
-        while (!_isFinish && _renderThread) std::this_thread::yield();
+        if (_renderThread && _renderThread->joinable()) _renderThread->join();
+        _isFinish = true;
     }
+    // Text of the library error that stopped the render loop; empty while all is well.  Read it after
+    // isUpdateFinish() returned true.
+    bool failed() const { return _failed; }
+    const std::string& error() const { return _error; }
     // src/cpu/Integrator.cpp:21-24: hand the finished frame over (width*height*4 floats)
     void sync(float* rgba_dst) { std::memcpy(rgba_dst, _frame.data(), _frame.size() * sizeof(float)); }
 
@@ -88,6 +98,7 @@ class HipPathTracer {
         if (rt_set_camera(_ctx, _pos, _right, _up, _forward) != RT_OK || rt_render(_ctx, _passes) != RT_OK ||
             rt_read_film(_ctx, _frame.data()) != RT_OK) {
             _error = rt_last_error(_ctx);
+            _failed = true;
             _isRun = false;
             return;
         }
@@ -104,4 +115,5 @@ class HipPathTracer {
     std::shared_ptr<std::thread> _renderThread;
     std::atomic_bool _isFinish{true};
     std::atomic_bool _isRun{true};
+    std::atomic_bool _failed{false};
 };

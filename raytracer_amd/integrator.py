@@ -30,40 +30,46 @@ class HipPathTracer:
         self._frames = 0
         self.error = None
 
-    # src/cpu/Integrator.cpp:69-79
+    # src/cpu/Integrator.cpp:69-79.  The thread leaves _isFinish set whichever way it ends.
     def run(self):
         def loop():
-            while self._isRun:
-                if not self._isFinish:
-                    try:
-                        self.update()
-                    except Exception as e:  # surface the library's error to the caller's thread
-                        self.error = e
-                        self._isRun = False
-                    self._isFinish = True
-                else:
-                    time.sleep(0)
-        self._thread = threading.Thread(target=loop, daemon=True)
-        self._thread.start()
+            try:
+                while self._isRun:
+                    if not self._isFinish:
+                        try:
+                            self.update()
+                        except Exception as e:  # surface the library's error to the caller's thread
+                            self.error = e
+                            self._isRun = False
+                        self._isFinish = True
+                    else:
+                        time.sleep(0)
+            finally:
+                self._isFinish = True
+        if self._thread is None:
+            self._thread = threading.Thread(target=loop, daemon=True)
+            self._thread.start()
 
     def isUpdateFinish(self) -> bool:
         return self._isFinish
 
-    # src/cpu/Integrator.cpp:85-92
+    # src/cpu/Integrator.cpp:85-92; does nothing after an error or after finish()
     def nextFrame(self, camera: Camera):
+        if self.error is not None or not self._isRun:
+            return
         r, f = camera.right.astype(np.float32), camera.forward.astype(np.float32)
         c = np.array([r[1] * f[2] - f[1] * r[2], r[2] * f[0] - f[2] * r[0], r[0] * f[1] - f[0] * r[1]], np.float32)
         up = c * (np.float32(1.0) / np.sqrt(np.float32(c[0] * c[0] + c[1] * c[1] + c[2] * c[2])))
         self._camera = Camera(camera.pos.astype(np.float32), r, up.astype(np.float32), f)
         self._isFinish = False
 
-    # src/cpu/Integrator.cpp:94-97
+    # src/cpu/Integrator.cpp:94-97: stops the loop and joins the thread (never waits on _isFinish, which a thread that
+    # has already left its loop would not set)
     def finish(self):
         self._isRun = False
-        while not self._isFinish and self._thread is not None:
-            time.sleep(0)
         if self._thread is not None:
-            self._thread.join(5)
+            self._thread.join()
+        self._isFinish = True
 
     def getTexture(self) -> np.ndarray:
         return self._texture

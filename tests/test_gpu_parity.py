@@ -151,8 +151,8 @@ def test_untame_rays_take_the_exact_path(atrium_small):
 
 
 def test_render_depth8_larger_film_matches_oracle(atrium_small):
-    """Deeper paths on a film large enough to keep both streams of a pass busy
-    (the shadow chain overlaps the next bounce's extend/shade)."""
+    """Deeper paths on a film large enough that every bounce's merged launch
+    (shadow rays of bounce d + closest-hit rays of bounce d+1) spans many workgroups."""
     W, H = 480, 270
     ctx, orc = Context(atrium_small, W, H, max_depth=8, seed=11), OracleScene(atrium_small)
     ctx.set_camera(atrium_small.camera)
@@ -169,7 +169,8 @@ def test_render_depth8_larger_film_matches_oracle(atrium_small):
 
 def test_render_is_deterministic_at_full_size():
     """Two renders of the 1080p Sponza-class workload must agree bit for bit
-    (any race between the two streams of a pass would show up here), and the
+    (a race between workgroups appending to the next-bounce arrays or marking
+    shadow entries would show up here), and the
     tile-sharded render of rank 0 of 2 must equal the same pixels of the
     unsharded one."""
     scene = scenes.sponza_class(env_size=(512, 256))

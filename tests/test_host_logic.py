@@ -149,3 +149,123 @@ def test_sponza_class_shape():
     assert ext == pytest.approx([37, 15, 23], abs=0.6)
     assert 15 <= s.n_models <= 30
     assert s.tri_model.max() == s.n_models - 1
+
+
+class _StubContext:
+    """Stands in for api.Context in the adapter protocol tests: render() fails from the n-th call on."""
+
+    def __init__(self, fail_from=1):
+        self.calls, self.fail_from = 0, fail_from
+
+    def set_camera(self, cam):
+        pass
+
+    def render(self, n):
+        self.calls += 1
+        if self.calls >= self.fail_from:
+            raise api.RtError(-4, "forced")
+
+    def read_film(self):
+        return np.zeros((4, 4, 4), np.float32)
+
+    def close(self):
+        pass
+
+
+def _stub_adapter(fail_from):
+    from raytracer_amd.integrator import HipPathTracer
+    pt = object.__new__(HipPathTracer)
+    pt._passes, pt._ctx = 1, _StubContext(fail_from)
+    pt._width = pt._height = 4
+    pt._frame = np.zeros((4, 4, 4), np.float32)
+    pt._texture = np.zeros((4, 4, 4), np.float32)
+    pt._isFinish, pt._isRun, pt._camera, pt._thread, pt._frames, pt.error = True, True, None, None, 0, None
+    return pt
+
+
+def _wait(pred, seconds=5.0):
+    import time
+    t0 = time.time()
+    while not pred() and time.time() - t0 < seconds:
+        time.sleep(0.001)
+    return pred()
+
+
+def test_adapter_close_returns_after_a_render_error(cornell):
+    pt = _stub_adapter(fail_from=2)
+    pt.nextFrame(cornell.camera)
+    pt.run()
+    assert _wait(pt.isUpdateFinish)
+    assert pt.error is None and pt.frames == 1
+    pt.nextFrame(cornell.camera)          # this update fails
+    assert _wait(lambda: pt.error is not None)
+    assert _wait(pt.isUpdateFinish)
+    pt.nextFrame(cornell.camera)          # ignored after an error: the frame stays finished
+    assert pt.isUpdateFinish()
+    pt.close()                            # must not hang
+    assert not pt._thread.is_alive()
+
+
+def test_adapter_finish_right_after_next_frame_returns(cornell):
+    pt = _stub_adapter(fail_from=10 ** 9)
+    pt.run()
+    pt.nextFrame(cornell.camera)
+    pt.finish()                           # whether or not the thread picked the frame up
+    assert pt.isUpdateFinish() and not pt._thread.is_alive()
+    pt.nextFrame(cornell.camera)          # no thread left: ignored
+    assert pt.isUpdateFinish()
+
+
+def test_cpp_adapter_shutdown_with_a_failing_library(tmp_path):
+    """HipPathTracer.hpp against a stub of the C-ABI whose rt_render fails on the second call: error() is set,
+    nextFrame() is ignored afterwards, finish() and the destructor return."""
+    import subprocess
+    stub = tmp_path / "stub.cpp"
+    stub.write_text(r'''
+#include "raytracer_amd/host/HipPathTracer.hpp"
+#include <chrono>
+#include <cstdio>
+static int g_calls = 0;
+extern "C" {
+int rt_create(const rt_scene_desc*, const rt_params*, rt_ctx** out) { *out = reinterpret_cast<rt_ctx*>(&g_calls); return 0; }
+void rt_destroy(rt_ctx*) {}
+const char* rt_last_error(const rt_ctx*) { return "forced failure"; }
+int rt_set_camera(rt_ctx*, const float*, const float*, const float*, const float*) { return 0; }
+int rt_render(rt_ctx*, uint32_t) { return ++g_calls >= 2 ? RT_ERR_LIMIT : RT_OK; }
+int rt_read_film(rt_ctx*, float*) { return 0; }
+}
+static bool wait_finish(HipPathTracer& pt) {
+    auto t0 = std::chrono::steady_clock::now();
+    while (!pt.isUpdateFinish())
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) return false;
+    return true;
+}
+int main() {
+    rt_scene_desc sd{};
+    const float pos[3] = {0, 0, 0}, right[3] = {1, 0, 0}, fwd[3] = {0, 0, -1};
+    {
+        HipPathTracer pt(sd, 4, 4);
+        pt.nextFrame(pos, right, fwd);
+        pt.run();
+        if (!wait_finish(pt) || pt.failed()) return 1;
+        pt.nextFrame(pos, right, fwd);
+        if (!wait_finish(pt) || !pt.failed() || pt.error() != "forced failure") return 2;
+        pt.nextFrame(pos, right, fwd);
+        if (!pt.isUpdateFinish()) return 3;
+        pt.finish();
+    }
+    {
+        HipPathTracer pt(sd, 4, 4);
+        pt.run();
+        pt.nextFrame(pos, right, fwd);
+        pt.finish();
+        if (!pt.isUpdateFinish()) return 4;
+    }
+    std::puts("ok");
+    return 0;
+}
+''')
+    exe = tmp_path / "stub"
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-I", ROOT, "-o", str(exe), str(stub)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=30)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", (out.returncode, out.stdout, out.stderr)
