@@ -222,6 +222,23 @@ int rt_trace_closest_dev(rt_ctx* ctx, uint32_t n, const float* d_rays_soa, float
 int rt_trace_occluded_dev(rt_ctx* ctx, uint32_t n, const float* d_rays_soa, int32_t* d_status,
                           uint32_t repeat);
 
+/* rt_trace_closest_dev for callers that cannot allocate device memory (code
+ * under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc): it has no counterpart in the reference.  Same inputs, outputs
+ * and results as rt_trace_closest_dev with repeat = 1, but the launch's work
+ * counters and its list of rays for the exact follow-up launch live in a fixed
+ * array inside the library (16 MiB + 1.25 KiB per device, held until the
+ * process ends) instead of memory the context grows on demand, so the call
+ * never allocates, frees or synchronises: it enqueues on the context's stream
+ * and returns (rt_synchronize waits; rt_stats.last_trace_ms is not updated).
+ * At most RT_NOALLOC_MAX_RAYS rays per call, RT_ERR_LIMIT beyond.  Every call
+ * on a GPU shares that GPU's array, whichever context makes it: calls that
+ * overlap on one GPU (two contexts, two threads) race; calls through one
+ * context are ordered by its stream. */
+#define RT_NOALLOC_MAX_RAYS (1u << 22)
+int rt_trace_closest_noalloc(rt_ctx* ctx, uint32_t n, const float* d_rays_soa, float* d_dist,
+                             int32_t* d_id0, int32_t* d_id1, float* d_u, float* d_v);
+
 /* The LBVH in the reference's node layout (src/scene/BBox.hpp:27-56), for
  * checking tree identity: boxes n*6 floats (min xyz, max xyz); left, right,
  * tri (triIds[0]), model (modelIds[0]), leaf: n int32 each.  Pass nulls to

@@ -60,6 +60,7 @@ class rt_params(C.Structure):
 
 
 RT_FLAG_HOST_BVH = 1
+RT_NOALLOC_MAX_RAYS = 1 << 22   # rays per rt_trace_closest_noalloc call
 
 
 class rt_stats(C.Structure):
@@ -75,7 +76,7 @@ EXPORTS = [
     "rt_read_film", "rt_film_slab", "rt_copy_film_slab", "rt_unpack_slabs", "rt_unpack_slabs_dev", "rt_trace_closest",
     "rt_trace_occluded", "rt_trace_closest_dev", "rt_trace_occluded_dev", "rt_get_bvh", "rt_get_stats",
     "rt_synchronize", "rt_version", "rt_lbvh_host", "rt_morton3d", "rt_last_trace_ms", "rt_slab_floats", "rt_pack_slab",
-    "rt_read_primary_duv", "rt_trace_occluded_bounded", "rt_read_last_bounce_rays",
+    "rt_read_primary_duv", "rt_trace_occluded_bounded", "rt_read_last_bounce_rays", "rt_trace_closest_noalloc",
 ]
 
 
@@ -118,6 +119,7 @@ def load_library():
     lib.rt_trace_occluded_bounded.argtypes = [vp, C.c_uint32, fp, fp, ip]
     lib.rt_trace_closest_dev.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp, C.c_uint32]
     lib.rt_trace_occluded_dev.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32]
+    lib.rt_trace_closest_noalloc.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
     lib.rt_get_bvh.argtypes = [vp, up, fp, ip, ip, ip, ip, ip]
     lib.rt_get_stats.argtypes = [vp, C.POINTER(rt_stats)]
     lib.rt_synchronize.argtypes = [vp]
@@ -285,6 +287,10 @@ class Context:
 
     def trace_closest_dev(self, n: int, d_rays: int, d_t: int, d_id0: int, d_id1: int, d_u: int, d_v: int, repeat: int = 1):
         self._check(self._lib.rt_trace_closest_dev(self._h, n, d_rays, d_t, d_id0, d_id1, d_u, d_v, repeat))
+
+    def trace_closest_noalloc(self, n: int, d_rays: int, d_t: int, d_id0: int, d_id1: int, d_u: int, d_v: int):
+        """rt_trace_closest_noalloc: enqueues on the context's stream and returns; call synchronize() before reading."""
+        self._check(self._lib.rt_trace_closest_noalloc(self._h, n, d_rays, d_t, d_id0, d_id1, d_u, d_v))
 
     def trace_occluded_dev(self, n: int, d_rays: int, d_status: int, repeat: int = 1):
         self._check(self._lib.rt_trace_occluded_dev(self._h, n, d_rays, d_status, repeat))

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,9 +19,42 @@
 
 using namespace rt;
 
+#ifndef RT_NOALLOC_MAX_RAYS
+#define RT_NOALLOC_MAX_RAYS (1u << 22)   // 4,194,304 rays: 16 MiB of deferred list + the work counters
+#endif
+
+// Scratch of rt_trace_closest_noalloc: the work counters of one traversal launch followed by the list of rays
+// handed to the exact follow-up launch (one index per ray at most).  File scope, so the entry point never
+// allocates; every device the library runs on holds its own copy until the process ends.
+constexpr uint32_t kNoAllocMaxRays = RT_NOALLOC_MAX_RAYS;
+constexpr size_t kNoAllocWorkBytes = (sizeof(rt::TraceWork) + 255) / 256 * 256;
+constexpr size_t kNoAllocBytes = kNoAllocWorkBytes + (size_t)kNoAllocMaxRays * sizeof(uint32_t);
+static __device__ __align__(256) unsigned char scratch[kNoAllocBytes];
+
+
 namespace {
 
 thread_local std::string g_create_error;
+
+// Device address of `scratch` on each device (the array's name is only a host-side handle: never pass it to a
+// kernel or a memset).  Filled once per device by scratch_address(), with that device current.
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};
+
+// Call with `device` current.  Returns nullptr and sets *e on failure.
+unsigned char* scratch_address(int device, hipError_t* e) {
+    *e = hipSuccess;
+    if (device < 0 || device >= kMaxDevices) { *e = hipErrorInvalidDevice; return nullptr; }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        *e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (*e != hipSuccess) return nullptr;
+        g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    return g_scratch_ptr[device];
+}
 
 struct EnvTables {
     float4* img = nullptr;
@@ -109,6 +143,8 @@ struct rt_ctx {
     float* d_tr_rays = nullptr;
     float* d_tr_out = nullptr;  // t,u,v planes + id0,id1 planes
     uint32_t tr_cap = 0;
+
+    unsigned char* scratch_ptr = nullptr;      // this device's copy of the file-scope scratch array
 
     float last_trace_ms = 0.f, last_render_ms = 0.f, bvh_build_ms = 0.f;
 };
@@ -509,6 +545,11 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     HIP_TRY(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIP_TRY(c, hipEventCreate(&c->ev0));
     HIP_TRY(c, hipEventCreate(&c->ev1));
+    {
+        hipError_t se;
+        c->scratch_ptr = scratch_address(c->device, &se);
+        HIP_TRY(c, se);
+    }
 
     // ---- BVH: built on the GPU unless the caller asks for the host builder
     auto t0 = std::chrono::steady_clock::now();
@@ -1058,6 +1099,31 @@ int rt_trace_closest_dev(rt_ctx* c, uint32_t n, const float* d_rays, float* d_t,
     if (n == 0) return RT_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     return launch_closest(c, n, d_rays, d_t, d_id0, d_id1, d_u, d_v, repeat);
+}
+
+int rt_trace_closest_noalloc(rt_ctx* c, uint32_t n, const float* d_rays, float* d_t, int32_t* d_id0, int32_t* d_id1, float* d_u,
+                             float* d_v) {
+    if (!c || !d_rays || !d_t || !d_id0 || !d_id1 || !d_u || !d_v) return RT_ERR_ARG;
+    if (n == 0) return RT_OK;
+    if (n > kNoAllocMaxRays) {
+        char b[160];
+        snprintf(b, sizeof b, "rt_trace_closest_noalloc: %u rays exceed the fixed scratch of %u rays (use rt_trace_closest_dev)", n,
+                 kNoAllocMaxRays);
+        c->err = b;
+        return RT_ERR_LIMIT;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    // the device address taken at rt_create, never the array's name
+    TraceWork* work = reinterpret_cast<TraceWork*>(c->scratch_ptr);
+    uint32_t* deferred = reinterpret_cast<uint32_t*>(c->scratch_ptr + kNoAllocWorkBytes);
+    // the array keeps the last call's counters: they must start at zero (the list is rewritten before it is read)
+    HIP_TRY(c, hipMemsetAsync(work, 0, sizeof(TraceWork), c->stream));
+    hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, work, deferred, d_t,
+                       d_id0, d_id1, d_u, d_v, c->d_raystats);
+    hipLaunchKernelGGL(k_trace_closest<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, work, deferred, d_t,
+                       d_id0, d_id1, d_u, d_v, c->d_raystats);
+    HIP_TRY(c, hipGetLastError());
+    return RT_OK;
 }
 
 int rt_trace_occluded_dev(rt_ctx* c, uint32_t n, const float* d_rays, int32_t* d_status, uint32_t repeat) {
