@@ -24,9 +24,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
-# fp32 vector peak in lane-operations/s: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz (an FMA counts once: the path may
-# not contract, so every multiply and add is its own instruction)
-VALU_PEAK_TOPS = 256 * 4 * 16 * 2.4e9 / 1e12
+# fp32 vector peak of this path in lane-operations/s: 256 CUs x 4 SIMDs x 32 lanes per cycle x 2.4 GHz = 78.6 T.  A
+# wave64 VALU instruction issues over 2 cycles on a SIMD-32 (tools/ubench/valu_ubench.hip measures 2.3-2.5 cycles at
+# the nominal clock with 8 waves per SIMD: profiles/r02/valu_ubench.json).  An FMA would count twice (157.3 TFLOP/s
+# is the datasheet figure), but the path may not contract a*b+c, so every multiply and add is an instruction of its
+# own and one lane-operation per lane and issue slot is the ceiling.
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 
 
 def algorithmic_bytes(n_rays: int, n_inner: int, n_tri: int) -> float:
@@ -52,6 +55,26 @@ def cpu_model() -> str:
     return "unknown"
 
 
+def launch_ranks(n_gpus: int, argv) -> int:
+    """Starts one rank per GPU as fresh child processes (torch.distributed.run over 127.0.0.1) and returns their
+    exit code.  Nothing here initialises a GPU: counting devices does not."""
+    import socket
+    import subprocess
+    import torch
+    have = torch.cuda.device_count()
+    if have < n_gpus:
+        print(f"bench.py: --gpus {n_gpus} asked for but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +89,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be at least 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started as a plain script: become the launcher of N rank processes (before anything touches a GPU)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print there (RCCL's version banner)
+    # goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -74,6 +108,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -167,37 +203,55 @@ def main():
         }
 
     # ---- tile-sharded leg (BASELINE.json configs[3] shape): ONE film split over the ranks by interleaved tiles,
-    # no exchange while rendering, one all-gather of the tile slabs over RCCL at read-out.  Strong scaling; it is a
-    # side report and must never take the headline down with it.
+    # no exchange while rendering, one all-gather of the tile slabs over RCCL at read-out.  Strong scaling.  Part of
+    # every N > 1 run: a failure here fails the run.
     sharded = None
     if use_dist and args.render_passes > 0 and (world > 1 or os.environ.get("BENCH_FORCE_SHARDED") == "1"):
-        try:
-            from raytracer_amd.dist import gather_film
-            SW, SH = 2 * W, 2 * H
-            sctx = Context(scene, SW, SH, max_depth=args.render_depth, seed=0, device=local_rank, rank=rank, world=world)
-            sctx.set_camera(scene.camera)
-            sctx.render(args.render_passes)  # warm-up
-            gather_film(sctx)
-            sctx.reset_accumulation()
-            barrier()
-            g0 = time.perf_counter()
-            sctx.render(args.render_passes)
-            sctx.synchronize()
-            g1 = time.perf_counter()
-            film = gather_film(sctx)
-            barrier()
-            g2 = time.perf_counter()
-            t = torch.tensor([g2 - g0, g2 - g1], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tot, gat = float(t[0].item()), float(t[1].item())
-            sharded = {"workload": f"sponza_class {SW}x{SH}, depth {args.render_depth}, {args.render_passes} passes, film sharded by "
-                                   f"64x64 tiles over {world} GPU(s), slabs all-gathered over RCCL", "scaling": "strong",
-                       "samples_per_sec": SW * SH * args.render_passes / tot, "ms_per_pass": tot / args.render_passes * 1e3,
-                       "gather_ms": gat * 1e3, "film_finite": bool(np.isfinite(film).all()),
-                       "film_mean": float(film[..., :3].mean())}
-            sctx.close()
-        except Exception as e:  # noqa: BLE001
-            sharded = {"error": repr(e)}
+        from raytracer_amd.dist import gather_film
+        SW, SH = 2 * W, 2 * H
+        sctx = Context(scene, SW, SH, max_depth=args.render_depth, seed=0, device=local_rank, rank=rank, world=world)
+        sctx.set_camera(scene.camera)
+        sctx.render(args.render_passes)  # warm-up
+        gather_film(sctx)
+        sctx.reset_accumulation()
+        barrier()
+        g0 = time.perf_counter()
+        sctx.render(args.render_passes)
+        sctx.synchronize()
+        g1 = time.perf_counter()
+        film = gather_film(sctx)
+        barrier()
+        g2 = time.perf_counter()
+        t = torch.tensor([g2 - g0, g2 - g1], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tot, gat = float(t[0].item()), float(t[1].item())
+        # the gathered film against rank-local renders, bit for bit: this rank's own tiles, and the tiles of the
+        # next rank rendered here again by a second context
+        ty, tx = np.mgrid[0:SH, 0:SW]
+        owner = ((ty // 64) * (-(-SW // 64)) + tx // 64) % world
+        mine = sctx.read_film()
+        bad = int((film.view(np.uint32)[owner == rank] != mine.view(np.uint32)[owner == rank]).any(-1).sum())
+        other = (rank + 1) % world
+        if other != rank:
+            octx = Context(scene, SW, SH, max_depth=args.render_depth, seed=0, device=local_rank, rank=other, world=world)
+            octx.set_camera(scene.camera)
+            octx.render(args.render_passes)
+            theirs = octx.read_film()
+            octx.close()
+            bad += int((film.view(np.uint32)[owner == other] != theirs.view(np.uint32)[owner == other]).any(-1).sum())
+        tb = torch.tensor([bad], dtype=torch.int64, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        sharded = {"workload": f"sponza_class {SW}x{SH}, depth {args.render_depth}, {args.render_passes} passes, film sharded by "
+                               f"64x64 tiles over {world} GPU(s), slabs all-gathered over RCCL", "scaling": "strong",
+                   "samples_per_sec": SW * SH * args.render_passes / tot, "ms_per_pass": tot / args.render_passes * 1e3,
+                   "gather_ms": gat * 1e3, "film_finite": bool(np.isfinite(film).all()),
+                   "film_mean": float(film[..., :3].mean()),
+                   "pixels_differing_from_rank_local_renders": int(tb.item())}
+        sctx.close()
+        if int(tb.item()) != 0 or not sharded["film_finite"]:
+            print(f"bench.py: tile-sharded film differs from the rank-local renders: {sharded}", file=sys.stderr)
+            dist.destroy_process_group()
+            sys.exit(3)
 
     if rank != 0:
         if use_dist:
@@ -256,28 +310,56 @@ def main():
             same = (g_film.view(np.uint32) == o_film.view(np.uint32)) | (np.isnan(g_film) & np.isnan(o_film))
             render["film_parity"] = {"passes": 1, "pixels": rw * rh, "bit_identical": bool(same.all()),
                                      "pixels_differing": int((~same).any(-1).sum())}
-        tot_bytes = sum(algorithmic_bytes(n, counts[k]["n_inner"], counts[k]["n_tri"]) for k in counts)
+        n_inner = sum(counts[k]["n_inner"] for k in counts)
+        n_tri = sum(counts[k]["n_tri"] for k in counts)
+        tot_bytes = algorithmic_bytes(NS * n, n_inner, n_tri)
+        tot_ops = algorithmic_valu_ops(NS * n, n_inner, n_tri)
         launch_ms = float(np.mean(kernel_ms))
-        achieved = tot_bytes / (launch_ms * 1e-3) / 1e9
+        secs = launch_ms * 1e-3
+        # Candidate bounds of the launch, each as algorithmic work / launch time / peak:
+        #  * valu: the slab and triangle arithmetic of the reference's algorithm against the fp32 vector rate;
+        #  * hbm: the bytes that must cross HBM once per launch -- rays in, hits out, and every node and triangle
+        #    once (the tree is cache-resident: 56 B per visit are NOT HBM bytes) -- against 8 TB/s;
+        # plus, as a diagnostic, the per-visit byte model against HBM peak (above 1: a cache-less machine could not
+        # run this launch in this time; it says the caches work, it is not a bound).
+        st = ctx.stats()
+        tree_bytes = 64.0 * (st["n_triangles"] - 1) + 48.0 * st["n_triangles"]
+        compulsory = 44.0 * NS * n + tree_bytes
         traffic = None
-        counters = None   # pipe utilisation of the same kernel from the committed rocprofv3 --pmc passes
+        counters = None   # pipe utilisation of the same kernel from committed rocprofv3 --pmc passes (not this run)
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
-            try:
-                tj = json.load(open(tp))
-                traffic = tj.get("k_trace_closest_bytes_per_launch")
-                counters = {k: tj[k] for k in ("tcc_hit_rate", "valu_issue_busy", "ta_busy", "valu_active_lane_fraction",
-                                               "valu_instructions_per_ray", "rocprof_avg_launch_us") if k in tj}
-            except Exception:
-                traffic = None
-        valu_tops = sum(algorithmic_valu_ops(n, counts[k]["n_inner"], counts[k]["n_tri"]) for k in counts) / (launch_ms * 1e-3) / 1e12
-        roofline = {"bound": "hbm", "kernel": "k_trace_closest", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "counters": counters,
-                    # the second candidate bound of this path, by the same convention (algorithmic work / launch time)
-                    "valu": {"achieved": valu_tops, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s", "frac": valu_tops / VALU_PEAK_TOPS},
-                    "bytes_per_launch": tot_bytes, "avg_launch_ms": launch_ms, "rays_per_launch": NS * n,
+            tj = json.load(open(tp))
+            traffic = tj.get("k_trace_closest_bytes_per_launch")
+            counters = {k: tj[k] for k in ("tcc_hit_rate", "valu_issue_busy", "ta_busy", "valu_active_lane_fraction",
+                                           "valu_instructions_per_ray", "rocprof_avg_launch_us") if k in tj}
+            counters["source"] = "profiles/traffic.json: " + tj.get("source", "")
+        cand = {
+            "valu": {"achieved": tot_ops / secs / 1e12, "peak": VALU_PEAK_TOPS, "unit": "TFLOP/s",
+                     "frac": tot_ops / secs / 1e12 / VALU_PEAK_TOPS, "ops_per_launch": tot_ops,
+                     "note": "fp32 lane-operations (no FMA: the path may not contract); 54 per inner visit, 57 per triangle "
+                             "test, 12 per ray; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz"},
+            "hbm": {"achieved": compulsory / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": compulsory / secs / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": compulsory,
+                    "note": "compulsory bytes: 44 B per ray + the node and triangle arrays once"},
+        }
+        if traffic:
+            cand["hbm_measured"] = {"achieved": traffic / (counters["rocprof_avg_launch_us"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": traffic / (counters["rocprof_avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "bytes beyond L2 (FETCH_SIZE + WRITE_SIZE) of the profiled launch / its duration"}
+            cand["l1_address_path"] = {"frac": counters.get("ta_busy"), "note": "TA_TA_BUSY / cycles of the profiled launch"}
+        binding = max(("valu", "hbm"), key=lambda k: cand[k]["frac"])
+        b = cand[binding]
+        roofline = {"bound": binding, "kernel": "k_trace_closest", "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"],
+                    "frac": b["frac"], "traffic": traffic, "candidates": cand, "counters": counters,
+                    "per_visit_byte_model": {"bytes_per_launch": tot_bytes, "gbs": tot_bytes / secs / 1e9,
+                                             "over_hbm_peak": tot_bytes / secs / 1e9 / HBM_PEAK_GBS,
+                                             "note": "44 B per ray + 56 B per inner visit + 36 B per triangle test; the visits are "
+                                                     "served by LDS, L1, L2 and Infinity Cache, so this is not a bound"},
+                    "avg_launch_ms": launch_ms, "rays_per_launch": NS * n,
                     "per_set": {k: {"n_inner_per_ray": counts[k]["n_inner"] / n, "n_tri_per_ray": counts[k]["n_tri"] / n,
                                     "bytes_per_ray": algorithmic_bytes(n, counts[k]["n_inner"], counts[k]["n_tri"]) / n,
+                                    "valu_ops_per_ray": algorithmic_valu_ops(n, counts[k]["n_inner"], counts[k]["n_tri"]) / n,
                                     "launched_alone_ms": set_ms[k],
                                     "launched_alone_mrays_per_sec": n / set_ms[k] / 1e3} for k in counts}}
 
@@ -291,7 +373,9 @@ def main():
                    "rays_per_step": rays_per_step, "bvh": "reference LBVH, 1 triangle per leaf"},
         "roofline": roofline, "cpu_baseline": cpu_baseline, "sharded_render": sharded, "parity": parity, "render": render,
     }
-    print(json.dumps(line))
+    sys.stdout.flush()
+    with os.fdopen(json_fd, "w") as out:
+        out.write(json.dumps(line) + "\n")
     if use_dist:
         dist.destroy_process_group()
 

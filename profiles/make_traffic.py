@@ -31,8 +31,8 @@ def main(path):
                       "WRITE_SIZE taken as is. Counter unit: KiB.",
         "tcc_hit_rate": hit / (hit + miss),
         # pipe utilisation over the launch (cycles = GRBM_GUI_ACTIVE / 8 XCDs; a wave64 VALU instruction holds its
-        # SIMD for 4 cycles; TA_TA_BUSY summed over the 256 CUs)
-        "valu_issue_busy": c["SQ_INSTS_VALU"]["mean_per_launch"] * 4.0 / (1024.0 * c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0),
+        # SIMD-32 for 2 cycles (profiles/r02/valu_ubench.json); TA_TA_BUSY summed over the 256 CUs)
+        "valu_issue_busy": c["SQ_INSTS_VALU"]["mean_per_launch"] * 2.0 / (1024.0 * c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0),
         "ta_busy": c["TA_TA_BUSY_sum"]["mean_per_launch"] / (256.0 * c["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8.0),
         "valu_active_lane_fraction": c["SQ_THREAD_CYCLES_VALU"]["mean_per_launch"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]["mean_per_launch"]),
         "valu_instructions_per_ray": c["SQ_INSTS_VALU"]["mean_per_launch"] / RAYS_PER_LAUNCH,

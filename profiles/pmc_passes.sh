@@ -3,7 +3,7 @@
 # one --kernel-trace --stats run and separate --pmc passes (counters are never
 # combined with tracing in one run).  Usage: profiles/pmc_passes.sh <tag>
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT

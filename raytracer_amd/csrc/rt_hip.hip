@@ -95,7 +95,7 @@ struct rt_ctx {
     DevLight* d_lights = nullptr;
     int32_t* d_material_texture = nullptr;
     int32_t* d_material_glossy = nullptr;
-    bool any_glossy = false, any_area = false;
+    bool any_glossy = false, any_area = false, any_point = false;
     DevTexture* d_textures = nullptr;
     TexLevel* d_tex_levels = nullptr;
     uchar4* d_texels = nullptr;
@@ -137,6 +137,8 @@ struct rt_ctx {
     // camera / accumulation
     CameraK cam{};
     bool have_camera = false;
+    bool prim_valid = false;    // the per-camera cache (primary rays and hits, UV differences, point-light visibility) is filled
+    uint32_t* d_prime_count = nullptr;   // n_valid, as a device word for the primary-ray launch
     uint64_t frames = 0;
 
     // rt_trace_* staging (host-pointer variants)
@@ -356,7 +358,6 @@ int launch_occluded(rt_ctx* c, uint32_t n, const float* d_rays, int32_t* d_statu
 // film slot s of pass (frames + b).
 int run_pass(rt_ctx* c, uint32_t nb) {
     const int D = c->params.max_depth, L = c->n_lights;
-    const uint32_t n = c->n_total;
     const uint32_t pass = (uint32_t)c->frames;
     const uint64_t seed_mixed = [&] {
         uint64_t z = c->params.seed + 0x9E3779B97F4A7C15ull;
@@ -369,24 +370,33 @@ int run_pass(rt_ctx* c, uint32_t nb) {
     HIP_TRY(c, hipMemsetAsync(c->d_pass_work, 0, c->n_pass_work * sizeof(TraceWork), c->stream));
     const uint32_t live = nb * c->n_slots;
     const uint32_t gslots = (live + RT_BLOCK - 1) / RT_BLOCK;
+    const uint32_t g1 = (c->n_slots + RT_BLOCK - 1) / RT_BLOCK;
     c->pb.rays = c->d_rays[0]; c->pb.beta = c->d_beta[0]; c->pb.slot = c->d_slot[0];
     c->pb.rays_next = c->d_rays[1]; c->pb.beta_next = c->d_beta[1]; c->pb.slot_next = c->d_slot[1];
-    hipLaunchKernelGGL(k_generate, dim3(gslots), dim3(RT_BLOCK), 0, c->stream, c->pb, c->cam, live);
     const uint32_t gtrace = grid_for(c, nb * c->n_valid);
     const uint32_t gshade = std::min<uint32_t>(gslots, (uint32_t)c->num_cu * 8u);
-    // Primary rays, then per bounce: shade(d) -> ONE traversal launch carrying
-    // the shadow rays of bounce d and the closest-hit rays of bounce d+1 (both
-    // are ready once shade(d) has run) -> accumulate(d).  One persistent launch
+    TraceWork* work = c->d_pass_work;
+    // The first pass after a camera change fills the per-camera cache: the camera ray has no jitter
+    // (src/cpu/PathTracer.cpp:43-50), so primary rays, their hits and the quad UV differences are those of every
+    // later pass; they are traced once per film slot, not once per pass.
+    const int prime = c->prim_valid ? 0 : 1;
+    if (prime) {
+        hipLaunchKernelGGL(k_generate, dim3(g1), dim3(RT_BLOCK), 0, c->stream, c->pb, c->cam, c->n_slots);
+        // the first n_valid entries of d_q0 are the film slots of the batch's first pass
+        hipLaunchKernelGGL(k_extend<false>, dim3(grid_for(c, c->n_valid)), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.prim_rays, c->n_slots,
+                           c->d_q0, c->d_prime_count, work + D, c->d_pass_deferred, c->pb.prim_t, c->pb.prim_id0, c->pb.prim_id1, c->pb.prim_u,
+                           c->pb.prim_v, c->d_raystats);
+        hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.prim_rays, c->n_slots, c->d_q0,
+                           c->d_prime_count, work + D, c->d_pass_deferred, c->pb.prim_t, c->pb.prim_id0, c->pb.prim_id1, c->pb.prim_u,
+                           c->pb.prim_v, c->d_raystats);
+        if (c->n_textures && c->n_local_tiles)
+            hipLaunchKernelGGL(k_quad_duv, dim3(c->n_local_tiles), dim3(RT_BLOCK), 0, c->stream, c->pb, c->d_tri_attr, c->d_duv, c->tile,
+                               (float)c->params.width, (float)c->params.height);
+    }
+    // Per bounce: shade(d) -> ONE traversal launch carrying the shadow rays of bounce d and the closest-hit rays of
+    // bounce d+1 (both are ready once shade(d) has run) -> accumulate(d).  One persistent launch
     // per bounce means one drain per bounce; everything is ordered on one stream
     // (k_accumulate beside k_shade on a second stream measured 2 % slower).
-    TraceWork* work = c->d_pass_work;
-    hipLaunchKernelGGL(k_extend<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.rays, n, c->d_q0, c->d_counts, work + D,
-                       c->d_pass_deferred, c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v, c->d_raystats);
-    hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.rays, n, c->d_q0, c->d_counts,
-                       work + D, c->d_pass_deferred, c->pb.hit_t, c->pb.hit_id0, c->pb.hit_id1, c->pb.hit_u, c->pb.hit_v, c->d_raystats);
-    if (c->n_textures && c->n_local_tiles)
-        hipLaunchKernelGGL(k_quad_duv, dim3(nb * c->n_local_tiles), dim3(RT_BLOCK), 0, c->stream, c->pb, c->d_tri_attr, c->d_duv, c->tile,
-                           (float)c->params.width, (float)c->params.height);
     // Bounce 0 walks the slots inside the film (d_q0) with path index = slot;
     // from bounce 1 on the paths are the first counts[d] entries of the
     // current arrays (queue == nullptr).
@@ -399,10 +409,10 @@ int run_pass(rt_ctx* c, uint32_t nb) {
         pbd.rays = c->d_rays[cur]; pbd.beta = c->d_beta[cur]; pbd.slot = c->d_slot[cur];
         pbd.rays_next = c->d_rays[cur ^ 1]; pbd.beta_next = c->d_beta[cur ^ 1]; pbd.slot_next = c->d_slot[cur ^ 1];
         if (c->any_glossy)
-            hipLaunchKernelGGL(k_shade<true>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
+            hipLaunchKernelGGL(k_shade<true>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, prime, seed_mixed, pass, qin, cnt_in,
                                cnt_out, c->sq, c->d_raystats + 1);
         else
-            hipLaunchKernelGGL(k_shade<false>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, seed_mixed, pass, qin, cnt_in,
+            hipLaunchKernelGGL(k_shade<false>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, prime, seed_mixed, pass, qin, cnt_in,
                                cnt_out, c->sq, c->d_raystats + 1);
         TraceWork* w = work + d;
         if (d + 1 < D) {
@@ -423,6 +433,8 @@ int run_pass(rt_ctx* c, uint32_t nb) {
                                    w, c->d_pass_deferred_b, c->d_raystats + 1);
             }
         }
+        if (d == 0 && prime && c->any_point)
+            hipLaunchKernelGGL(k_cache_visibility, dim3(g1), dim3(RT_BLOCK), 0, c->stream, pbd, c->sq, c->d_lights, L);
         if (L > 0) hipLaunchKernelGGL(k_accumulate, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->sq, L, qin, cnt_in);
         if (d + 1 < D) {
             qin = nullptr;
@@ -435,6 +447,7 @@ int run_pass(rt_ctx* c, uint32_t nb) {
     hipLaunchKernelGGL(k_film, dim3((c->n_slots + RT_BLOCK - 1) / RT_BLOCK), dim3(RT_BLOCK), 0, c->stream, c->pb, frames_f, nb);
     HIP_TRY(c, hipGetLastError());
     c->frames += nb;
+    c->prim_valid = true;
     return RT_OK;
 }
 
@@ -745,7 +758,9 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
                 float il = 1.0f / std::sqrt(l2);
                 d.n[0] = cx * il; d.n[1] = cy * il; d.n[2] = cz * il;
                 c->any_area = true;
-            } else if (s.type != RT_LIGHT_POINT) {
+            } else if (s.type == RT_LIGHT_POINT) {
+                c->any_point = true;
+            } else {
                 c->err = "unsupported light type (point = 0, area = 2 and env = 3 are implemented)";
                 return RT_ERR_ARG;
             }
@@ -793,9 +808,9 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     {
         const uint64_t L1 = (uint64_t)std::max<uint32_t>(1, sd->n_lights);
         // bytes of path state per slot (rays, beta and slot ids twice; hit; L; vertex; status; pixel id; queue entry;
-        // deferred list; UV differences in textured scenes) and of shadow entries per slot and light (direction,
+        // deferred list) and of shadow entries per slot and light (direction,
         // contributions, state, deferred list, far bound with area lights)
-        const uint64_t per_slot = 144 + (sd->n_textures ? 16 : 0) + (41 + (c->any_area ? 4 : 0)) * L1;
+        const uint64_t per_slot = 144 + (41 + (c->any_area ? 4 : 0)) * L1;
         uint64_t S = pr->batch ? pr->batch : 16;
         const uint64_t one = std::max<uint64_t>(1, (uint64_t)c->n_slots);
         S = std::min<uint64_t>(S, std::max<uint64_t>(1, (48ull << 30) / (per_slot * one)));
@@ -832,13 +847,26 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     if ((r = dev_alloc(c, &c->pb.status, n))) return r;
     if ((r = dev_alloc(c, &c->pb.film, (size_t)c->n_slots))) return r;
     HIP_TRY(c, hipMemset(c->pb.film, 0, (c->n_slots ? c->n_slots : 1) * sizeof(float4)));
-    if (n) HIP_TRY(c, hipMemset(c->pb.rays, 0, n * 6 * sizeof(float)));
+    {
+        const size_t n1a = c->n_slots ? c->n_slots : 1;
+        if ((r = dev_alloc(c, &c->pb.prim_rays, 6 * n1a))) return r;
+        if ((r = dev_alloc(c, &c->pb.prim_t, n1a))) return r;
+        if ((r = dev_alloc(c, &c->pb.prim_id0, n1a))) return r;
+        if ((r = dev_alloc(c, &c->pb.prim_id1, n1a))) return r;
+        if ((r = dev_alloc(c, &c->pb.prim_u, n1a))) return r;
+        if ((r = dev_alloc(c, &c->pb.prim_v, n1a))) return r;
+        if (c->any_point && (r = dev_alloc(c, &c->pb.prim_vis, (size_t)sd->n_lights * n1a))) return r;
+        HIP_TRY(c, hipMemset(c->pb.prim_rays, 0, 6 * n1a * sizeof(float)));
+        if (n) HIP_TRY(c, hipMemset(c->pb.status, 0, n * sizeof(uint32_t)));   // slots outside the film stay 0 for good
+        const uint32_t nv = c->n_valid;
+        if ((r = dev_upload(c, &c->d_prime_count, &nv, 1))) return r;
+    }
     c->pb.slot_pixel = c->d_slot_pixel;
     c->pb.n = (uint32_t)n;
     c->pb.n1 = c->n_slots ? c->n_slots : 1;
     if (c->n_textures) {
-        if ((r = dev_alloc(c, &c->d_duv, n))) return r;
-        HIP_TRY(c, hipMemset(c->d_duv, 0, (n ? n : 1) * sizeof(float4)));   // dev_alloc rounds an empty array up to one element
+        if ((r = dev_alloc(c, &c->d_duv, (size_t)c->n_slots))) return r;
+        HIP_TRY(c, hipMemset(c->d_duv, 0, (c->n_slots ? c->n_slots : 1) * sizeof(float4)));   // dev_alloc rounds an empty array up to one element
         c->ss.duv = c->d_duv;
     }
 
@@ -900,7 +928,10 @@ int rt_set_camera(rt_ctx* c, const float pos[3], const float right[3], const flo
     k.W = c->params.width;
     k.H = c->params.height;
     // a moved camera restarts accumulation (src/cpu/Integrator.cpp:27-30)
-    if (!c->have_camera || memcmp(&k, &c->cam, sizeof k) != 0) c->frames = 0;
+    if (!c->have_camera || memcmp(&k, &c->cam, sizeof k) != 0) {
+        c->frames = 0;
+        c->prim_valid = false;   // primary hits, UV differences and point-light visibility belong to the old camera
+    }
     c->cam = k;
     c->have_camera = true;
     return RT_OK;

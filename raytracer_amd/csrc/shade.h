@@ -62,6 +62,18 @@ struct PathBuffers {
     float4* film;       // n1 entries: one per film pixel slot
     uint32_t n;         // slots = plane stride: n1 * (passes traced together)
     uint32_t n1;        // slots of one pass; slot s belongs to pass s / n1 of the batch and to film slot s % n1
+    // What cannot change from pass to pass while the camera stands still, per FILM slot (n1 entries a plane): the
+    // camera ray has no jitter (src/cpu/PathTracer.cpp:43-50), so the primary ray and its hit are the same in every
+    // pass, and a point light's sample ignores the random numbers (src/lights/PointLight.cpp:14-18), so the shadow
+    // ray from the primary hit towards it is too.  Filled by the first pass after a camera change.
+    float* prim_rays;   // 6 planes of n1
+    float* prim_t;      // primary hit, by film slot
+    int32_t* prim_id0;
+    int32_t* prim_id1;
+    float* prim_u;
+    float* prim_v;
+    uint8_t* prim_vis;  // [light][n1]: shadow-entry state of the primary vertex towards each point light
+                        // (0 no ray, 1 occluded, 2 unoccluded)
 };
 
 // One mip level of a diffuse map inside the shared texel buffer.
@@ -709,17 +721,13 @@ RT_DEV uint32_t dim_light(int d, int L, int l, int k) { return (uint32_t)(d * (4
 RT_DEV uint32_t dim_bounce(int d, int L, int k) { return (uint32_t)(d * (4 * L + 2) + 4 * L + k); }
 
 // ---------------------------------------------------------------- kernels
-// Camera rays, src/cpu/PathTracer.cpp:43-52; also clears the per-pass state.
+// Camera rays, src/cpu/PathTracer.cpp:43-52, one per film slot of this rank (they do not depend on the pass).
 __global__ __launch_bounds__(RT_BLOCK) void k_generate(PathBuffers pb, CameraK cam, uint32_t count) {
     uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x;
     if (s >= count) return;
     uint32_t pix = pb.slot_pixel[s];
-    pb.status[s] = 0;
-    pb.slot[s] = s;
-    size_t n = pb.n;
-    pb.beta[s] = 1.f; pb.beta[n + s] = 1.f; pb.beta[2 * n + s] = 1.f;
-    pb.L[s] = 0.f; pb.L[n + s] = 0.f; pb.L[2 * n + s] = 0.f;
     if (pix == 0xFFFFFFFFu) return;
+    const size_t n = pb.n1;
     int x = (int)(pix % (uint32_t)cam.W), y = (int)(pix / (uint32_t)cam.W);
     float ni = ((float)x / (float)cam.W) - 0.5f;
     float nj = ((float)y / (float)cam.H) - 0.5f;
@@ -730,8 +738,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_generate(PathBuffers pb, CameraK c
     f3 fwd = mk3(cam.forward[0], cam.forward[1], cam.forward[2]);
     f3 ip = ni * right + nj * up + fwd;
     f3 d = normalize3(ip);
-    pb.rays[s] = cam.pos[0]; pb.rays[n + s] = cam.pos[1]; pb.rays[2 * n + s] = cam.pos[2];
-    pb.rays[3 * n + s] = d.x; pb.rays[4 * n + s] = d.y; pb.rays[5 * n + s] = d.z;
+    pb.prim_rays[s] = cam.pos[0]; pb.prim_rays[n + s] = cam.pos[1]; pb.prim_rays[2 * n + s] = cam.pos[2];
+    pb.prim_rays[3 * n + s] = d.x; pb.prim_rays[4 * n + s] = d.y; pb.prim_rays[5 * n + s] = d.z;
 }
 
 // UV differences of the primary hits, PASS 1/PASS 2 of
@@ -759,7 +767,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_quad_duv(PathBuffers pb, const flo
         int x = 2 * (q % qpr) + (id & 1), y = 2 * (q / qpr) + (id >> 1);
         return tile_base + (uint32_t)((((y >> 3) * bpr + (x >> 3)) << 6) + ((y & 7) << 3) + (x & 7));
     };
-    auto valid_of = [&](uint32_t s) -> bool { return pb.slot_pixel[s] != 0xFFFFFFFFu && pb.hit_id1[s] >= 0; };
+    auto valid_of = [&](uint32_t s) -> bool { return pb.slot_pixel[s] != 0xFFFFFFFFu && pb.prim_id1[s] >= 0; };
     int32_t last[4] = {-1, -1, -1, -1};
     for (int q = q_lo; q < q_hi; ++q)
 #pragma unroll
@@ -785,7 +793,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_quad_duv(PathBuffers pb, const flo
         int32_t ql = tid ? s_last[id][tid - 1] : -1;
         if (ql >= 0) {
             uint32_t s = slot_of(ql, id);
-            cur[id] = hit_uv(tri_attr, pb.hit_id1[s], pb.hit_u[s], pb.hit_v[s]);
+            cur[id] = hit_uv(tri_attr, pb.prim_id1[s], pb.prim_u[s], pb.prim_v[s]);
         }
     }
     for (int q = q_lo; q < q_hi; ++q) {
@@ -794,7 +802,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_quad_duv(PathBuffers pb, const flo
         for (int id = 0; id < 4; ++id) {
             uint32_t s = slot_of(q, id);
             ok[id] = valid_of(s);
-            if (ok[id]) cur[id] = hit_uv(tri_attr, pb.hit_id1[s], pb.hit_u[s], pb.hit_v[s]);
+            if (ok[id]) cur[id] = hit_uv(tri_attr, pb.prim_id1[s], pb.prim_u[s], pb.prim_v[s]);
         }
 #pragma unroll
         for (int id = 0; id < 4; ++id) {
@@ -827,8 +835,14 @@ struct ShadowQueue {
 // Material::computeBSDF (src/scene/Material.cpp:214-225), per-light sampling
 // with the contributions the reference would add once the shadow ray is
 // found unoccluded, then the BSDF bounce.
+//
+// At depth 0 the ray and its hit are the cached primary ones of the path's film slot (pb.prim_*), beta is one and
+// the path index is the slot.  `prime` != 0 is the first pass after a camera change: a primary ray that missed
+// writes the film (it does so once: nothing about it changes until the camera moves) and the shadow rays towards
+// point lights are traced, their outcome then being copied to pb.prim_vis by k_cache_visibility; with prime == 0
+// that outcome is taken from the cache and no such ray is queued.
 template <bool GLOSSY>
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene sc, int depth, int max_depth, uint64_t seed_mixed,
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene sc, int depth, int max_depth, int prime, uint64_t seed_mixed,
                                                     uint32_t first_pass, const uint32_t* __restrict__ queue,
                                                     const uint32_t* __restrict__ d_count, uint32_t* __restrict__ next_count,
                                                     ShadowQueue sq,
@@ -845,22 +859,39 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
         bool valid = i < count;
         // path index: the entries of `queue` at bounce 0 (slots inside the film), the entry number afterwards
         const uint32_t pi = valid ? (queue ? queue[i] : i) : 0u;
-        const uint32_t s = valid ? pb.slot[pi] : 0u;
+        const uint32_t s = valid ? (depth == 0 ? pi : pb.slot[pi]) : 0u;
+        const uint32_t fs = s % pb.n1;   // film slot
         bool hit = false;
         f3 org = mk3(0.f, 0.f, 0.f), dir = mk3(0.f, 0.f, 1.f);
         int32_t id0 = -1, id1 = -1;
+        float ht = 0.f, hu = 0.f, hv = 0.f;
         if (valid) {
-            org = mk3(pb.rays[pi], pb.rays[n + pi], pb.rays[2 * n + pi]);
-            dir = mk3(pb.rays[3 * n + pi], pb.rays[4 * n + pi], pb.rays[5 * n + pi]);
-            id1 = pb.hit_id1[pi];
-            id0 = pb.hit_id0[pi];
+            if (depth == 0) {
+                const size_t n1 = pb.n1;
+                org = mk3(pb.prim_rays[fs], pb.prim_rays[n1 + fs], pb.prim_rays[2 * n1 + fs]);
+                dir = mk3(pb.prim_rays[3 * n1 + fs], pb.prim_rays[4 * n1 + fs], pb.prim_rays[5 * n1 + fs]);
+                id1 = pb.prim_id1[fs];
+                id0 = pb.prim_id0[fs];
+                ht = pb.prim_t[fs]; hu = pb.prim_u[fs]; hv = pb.prim_v[fs];
+            } else {
+                org = mk3(pb.rays[pi], pb.rays[n + pi], pb.rays[2 * n + pi]);
+                dir = mk3(pb.rays[3 * n + pi], pb.rays[4 * n + pi], pb.rays[5 * n + pi]);
+                id1 = pb.hit_id1[pi];
+                id0 = pb.hit_id0[pi];
+                ht = pb.hit_t[pi]; hu = pb.hit_u[pi]; hv = pb.hit_v[pi];
+            }
             hit = id1 >= 0;
-            if (!hit && depth == 0) {
-                // src/cpu/PathTracer.cpp:61-65: the film takes the summed le, no accumulation
-                f3 Lm = mk3(0.f, 0.f, 0.f);
-                for (int l = 0; l < L; ++l) Lm = Lm + light_le(sc.lights[l], dir);
-                // every pass of a batch writes the same value here (the primary ray does not depend on the pass)
-                pb.film[s % pb.n1] = make_float4(Lm.x, Lm.y, Lm.z, 1.0f);
+            if (depth == 0) {
+                // per-pass state of the slot: the radiance sum starts at zero, status says whether the film
+                // takes the running mean (src/cpu/PathTracer.cpp:148-157)
+                pb.status[s] = hit ? 1u : 0u;
+                if (hit) { pb.L[s] = 0.f; pb.L[n + s] = 0.f; pb.L[2 * n + s] = 0.f; }
+                if (!hit && prime && s < pb.n1) {
+                    // src/cpu/PathTracer.cpp:61-65: the film takes the summed le, no accumulation
+                    f3 Lm = mk3(0.f, 0.f, 0.f);
+                    for (int l = 0; l < L; ++l) Lm = Lm + light_le(sc.lights[l], dir);
+                    pb.film[fs] = make_float4(Lm.x, Lm.y, Lm.z, 1.0f);
+                }
             }
         }
         BsdfK bsdf;
@@ -874,9 +905,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
         uint32_t pixel = 0;
         const uint32_t pass = first_pass + s / pb.n1;
         if (hit) {
-            if (depth == 0) pb.status[s] = 1;
             pixel = pb.slot_pixel[s];
-            float t = pb.hit_t[pi], hu = pb.hit_u[pi], hv = pb.hit_v[pi];
+            const float t = ht;
             float bc[3] = {1.0f - hu - hv, hu, hv};
             vpos = org + dir * t;
             const float* at = sc.tri_attr + (size_t)(id1 / 3) * 36;
@@ -917,7 +947,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
                 if (ti >= 0) {
                     const DevTexture tx = sc.textures[ti];
                     f2 ruv = fract2(uv);
-                    col = (depth == 0) ? tex_trilinear(sc, tx, ruv, sc.duv[s]) : tex_bilinear(sc, sc.tex_levels[tx.first_level], ruv);
+                    col = (depth == 0) ? tex_trilinear(sc, tx, ruv, sc.duv[fs]) : tex_bilinear(sc, sc.tex_levels[tx.first_level], ruv);
                 }
             }
             col = col / 255.0f;
@@ -937,7 +967,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
             }
             out = -dir;
             pb.vpos[pi] = vpos.x; pb.vpos[n + pi] = vpos.y; pb.vpos[2 * n + pi] = vpos.z;
-            beta = mk3(pb.beta[pi], pb.beta[n + pi], pb.beta[2 * n + pi]);
+            if (depth != 0) beta = mk3(pb.beta[pi], pb.beta[n + pi], pb.beta[2 * n + pi]);
         }
 
         // ---- light loop, src/cpu/PathTracer.cpp:96-125
@@ -980,8 +1010,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
             // a shadow ray that could only add exact zeros changes nothing whether
             // or not it is occluded (L + 0 == L), so it is not traced
             emit = emit && !(is_zero3(C) && is_zero3(C2));
-            n_emit += (uint32_t)__popcll(__ballot(emit));
-            if (valid) sq.state[(size_t)l * n + pi] = emit ? 1 : 0;
+            uint8_t st = emit ? 1 : 0;
+            bool traced = emit;
+            if (depth == 0 && !prime && hit && sc.lights[l].type == RT_LIGHT_POINT_K) {
+                // the ray from the primary vertex to a point light was resolved by the first pass
+                st = (pb.prim_vis[(size_t)l * pb.n1 + fs] == 2) ? 2 : 0;
+                emit = st == 2;
+                traced = false;
+            }
+            n_emit += (uint32_t)__popcll(__ballot(traced));
+            if (valid) sq.state[(size_t)l * n + pi] = st;
             if (emit) {
                 const size_t cap = sq.cap, e = (size_t)l * n + pi;
                 sq.dir[e] = in.x; sq.dir[cap + e] = in.y; sq.dir[2 * cap + e] = in.z;
@@ -1138,6 +1176,15 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_bounce(TraceScene ts,
         });
 }
 
+// After the traversal launch of bounce 0 in the first pass after a camera change: keeps, per film slot and point
+// light, what became of the shadow ray from the primary vertex (entries of the batch's first pass).
+__global__ __launch_bounds__(RT_BLOCK) void k_cache_visibility(PathBuffers pb, ShadowQueue q, const DevLight* __restrict__ lights, int n_lights) {
+    const uint32_t s = blockIdx.x * RT_BLOCK + threadIdx.x;
+    if (s >= pb.n1) return;
+    for (int l = 0; l < n_lights; ++l)
+        if (lights[l].type == RT_LIGHT_POINT_K) pb.prim_vis[(size_t)l * pb.n1 + s] = q.state[(size_t)l * pb.n + s];
+}
+
 // The adds of src/cpu/PathTracer.cpp:107/:109 and :123 for every path of the
 // bounce, light by light in the reference's loop order.
 __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(PathBuffers pb, ShadowQueue q, int n_lights, const uint32_t* __restrict__ queue,
@@ -1146,7 +1193,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_accumulate(PathBuffers pb, ShadowQ
     const size_t n = pb.n, cap = q.cap;
     for (uint32_t i = blockIdx.x * RT_BLOCK + threadIdx.x; i < count; i += gridDim.x * RT_BLOCK) {
         const uint32_t pi = queue ? queue[i] : i;
-        const uint32_t s = pb.slot[pi];
+        const uint32_t s = queue ? pi : pb.slot[pi];   // bounce 0 (the only one with a queue): path index = slot
         f3 Lp = mk3(pb.L[s], pb.L[n + s], pb.L[2 * n + s]);
         bool any = false;
         for (int l = 0; l < n_lights; ++l) {

@@ -145,8 +145,10 @@ def test_4k_tile_sharded_film_equals_unsharded_film():
     (lambda: scenes.cornell_area(), 100, 100, 16),
 ])
 def test_path_state_allocations_match_the_stated_budget(maker, W, H, batch):
-    """The device memory that grows with slots x batch is what rt_hip.h states: 144 B per slot (+16 B in textured
-    scenes) + 41 B per slot and light (+4 B with area lights), plus the film (16 B per slot of one pass)."""
+    """The device memory that grows with slots x batch is what rt_hip.h states: 144 B per slot + 41 B per slot and
+    light (+4 B with area lights); on top, per slot of ONE pass: the film (16 B), the per-camera cache (primary ray
+    and hit 44 B, one visibility byte per light when the scene has point lights) and the UV differences of
+    textured scenes (16 B)."""
     s = maker()
     ctx = Context(s, W, H, max_depth=4, batch=batch)
     st = ctx.stats()
@@ -155,8 +157,9 @@ def test_path_state_allocations_match_the_stated_budget(maker, W, H, batch):
     n1 = -(-W // 64) * -(-H // 64) * 64 * 64
     L = max(1, len(s.lights))
     area = any(l.type == scenes.LIGHT_AREA for l in s.lights)
-    per_slot = 144 + (16 if s.textures else 0) + (41 + (4 if area else 0)) * L
-    stated = per_slot * n1 * batch + 16 * n1
+    point = any(l.type == scenes.LIGHT_POINT for l in s.lights)
+    per_slot = 144 + (41 + (4 if area else 0)) * L
+    stated = per_slot * n1 * batch + (16 + 44 + (len(s.lights) if point else 0) + (16 if s.textures else 0)) * n1
     # the first-bounce queue holds only the slots inside the film (up to 4 B per slot fewer); the per-launch work
     # counters and queue counts are a few KiB on top
     assert stated - 4 * n1 * batch <= st["path_state_bytes"] <= stated + 65536

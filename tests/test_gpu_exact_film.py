@@ -72,3 +72,46 @@ def test_ragged_film_and_odd_tiles(cornell_env):
 
 def test_larger_film_many_passes(atrium_small):
     _exact(atrium_small, 480, 270, 8, 1, 3)
+
+
+def test_per_camera_cache_is_exact_and_follows_the_camera(cornell_env):
+    """Primary hits, quad UV differences and point-light visibility are kept while the camera stands still: passes
+    rendered one call at a time (the cache is filled by the first and used by the rest) leave the oracle's film, a
+    moved camera refills the cache, and the cached passes trace no primary rays and no rays towards point lights."""
+    s = scenes.with_textures(cornell_env)
+    W, H, depth, seed = 96, 80, 4, 6
+    orc = OracleScene(s)
+    ctx = Context(s, W, H, max_depth=depth, seed=seed, tile_size=32, batch=2)
+    ctx.set_camera(s.camera)
+    st0 = ctx.stats()
+    ctx.render(1)
+    st1 = ctx.stats()
+    ctx.render(1)
+    st2 = ctx.stats()
+    ctx.render(3)                      # a batch of 2 and a batch of 1
+    film = ctx.read_film()
+    ref, _ = orc.render(s.camera, W, H, depth, seed, 5)
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+    # pass 2 traced exactly one primary ray per pixel fewer than pass 1 would have without the cache; the oracle
+    # counts what a pass traces in full
+    _, c1 = orc.render(s.camera, W, H, depth, seed, 1)
+    assert st1["closest_rays"] - st0["closest_rays"] <= c1["closest"]
+    first, second = st1["closest_rays"] - st0["closest_rays"], st2["closest_rays"] - st1["closest_rays"]
+    assert 0 < second < first and first - second > W * H // 2   # bounce rays differ a little from pass to pass
+    assert st2["shadow_rays"] - st1["shadow_rays"] < st1["shadow_rays"] - st0["shadow_rays"]
+    # another camera, then back: every change restarts accumulation and refills the cache
+    cam2 = scenes.make_camera((0.3, 1.1, 3.0), (-0.1, -0.05, -1.0))
+    ctx.set_camera(cam2)
+    ctx.render(2)
+    ref2, _ = orc.render(cam2, W, H, depth, seed, 2)
+    assert np.array_equal(ctx.read_film().view(np.uint32), ref2.view(np.uint32))
+    ctx.set_camera(s.camera)
+    ctx.render(5)
+    assert np.array_equal(ctx.read_film().view(np.uint32), ref.view(np.uint32))
+    # the same camera again does not restart anything; a reset restarts the mean and keeps the cache
+    ctx.set_camera(s.camera)
+    assert ctx.stats()["passes"] == 5
+    ctx.reset_accumulation()
+    ctx.render(5)
+    assert np.array_equal(ctx.read_film().view(np.uint32), ref.view(np.uint32))
+    ctx.close()
