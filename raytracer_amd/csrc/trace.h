@@ -105,7 +105,9 @@ RT_DEV bool slab_test_fast(f3 org, f3 inv, float bx0, float by0, float bz0, floa
 }
 
 // Per-lane traversal stack: levels below RT_STACK_LDS in LDS, the rest in
-// the global overflow buffer.
+// the global overflow buffer.  (Putting the overflow accesses behind a
+// wave-uniform vote instead of a per-lane branch measured 1-4 % slower: some
+// lane of a wave is that deep most of the time.)
 struct LaneStack {
     int32_t* lds;      // &stack[tid]
     int32_t* ovf;      // &ovf[gtid]
@@ -225,15 +227,16 @@ struct TraceWork {
 // `continue` on several paths and a per-lane `have` flag made the compiler
 // treat the loop as divergent and copy all ~20 state registers twice per
 // iteration, about one inner step's worth of VALU work):
-//  * a lane's state is `cur` alone: RT_IDLE = no ray, >= 0 = inner node,
-//    otherwise ~triangle slot;
+//  * a lane's state is `cur` alone: RT_IDLE = no ray, RT_DONE = no ray but a result to write (the two
+//    smallest integers), >= 0 = inner node, otherwise ~triangle slot;
 //  * the chunk bounds and the exhausted flag go through readfirstlane at the
 //    top of every iteration, so every vote is a scalar branch and the loop has
 //    one uniform back edge;
-//  * a finished ray's result stays in the lane's registers (`dirty`) and is
+//  * a finished ray's result stays in the lane's registers (state RT_DONE) and is
 //    written when the lane is refilled (or after the loop), which keeps the
 //    five result stores out of the inner-node and triangle sections.
-#define RT_IDLE ((int32_t)0x80000000)
+#define RT_IDLE ((int32_t)0x80000000)   // no ray
+#define RT_DONE ((int32_t)0x80000001)   // no ray in flight, but the lane holds the unwritten result of its last ray
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 // 16 bytes at byte offset `off` of a buffer resource
@@ -272,7 +275,6 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
     // arrays reach 4 GiB; a fetch past the end would read zeros instead of faulting)
     const __amdgpu_buffer_rsrc_t rs_nodes = __builtin_amdgcn_make_buffer_rsrc((void*)sc.nodes, (short)0, (int)((uint32_t)sc.n_nodes * 64u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_tris = __builtin_amdgcn_make_buffer_rsrc((void*)sc.tris, (short)0, (int)((uint32_t)sc.n_tris * 48u), 0x00020000);
-    bool dirty = false;        // the lane holds the result of a finished ray that is not yet written
     int exhausted = 0;         // wave-uniform: the work counter ran past count
     uint32_t steal = 0;        // wave-uniform: ranges found empty so far (the XCD's own ranges come first)
     uint32_t c_next = 0, c_end = 0;  // wave-uniform: the chunk of items this wave is handing out
@@ -294,7 +296,7 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
         c_end = __builtin_amdgcn_readfirstlane(c_end);
         exhausted = __builtin_amdgcn_readfirstlane(exhausted);
         steal = __builtin_amdgcn_readfirstlane(steal);
-        const unsigned long long m_idle = __ballot(cur == RT_IDLE);
+        const unsigned long long m_idle = __ballot(cur <= RT_DONE);
         const int n_idle = __popcll(m_idle);
         if (n_idle >= RT_REFILL_MIN && (c_next < c_end || !exhausted)) {
             RT_PROBE_ADD(0, 1); RT_PROBE_ADD(1, n_idle);
@@ -330,8 +332,9 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                 const uint32_t avail = c_end - c_next;
                 const uint32_t k = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
                 const uint32_t r = __popcll(m_idle & ((1ull << lane) - 1ull));
-                if (cur == RT_IDLE && r < k) {
-                    if (dirty) { done(item, h); dirty = false; }
+                if (cur <= RT_DONE && r < k) {
+                    if (cur == RT_DONE) done(item, h);
+                    cur = RT_IDLE;
                     uint32_t i = c_next + r;
                     if (EXACT) i = deferred[i];
                     item = i;
@@ -354,7 +357,7 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                             deferred[atomicAdd(&work->n_deferred, 1u)] = i;
                         }
                     } else {
-                        dirty = true;
+                        cur = RT_DONE;   // missed the root box: the (empty) result is still to be written
                     }
                 }
                 c_next += k;
@@ -399,26 +402,28 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     const float bound = MIXED ? (any_lane ? tfar : h.t) : (BOUNDED ? tfar : h.t);
                     ls = ls && (ld < bound);
                     rs = rs && (rdist < bound);
+                    // src/scene/BVH.cpp:160-168: both hit -> nearer child first (left on a tie), the other one is
+                    // pushed; one hit -> that child; none -> back to the youngest pending child
+                    const bool swap = rdist < ld;
+                    int32_t nxt = (rs && (swap || !ls)) ? right : left;
                     if (ls && rs) {
-                        const bool swap = rdist < ld;
                         stk.push(sp, swap ? left : right);
                         ++sp;
-                        cur = swap ? right : left;
-                    } else if (ls || rs) {
-                        cur = ls ? left : right;
-                    } else if (sp > 0) {
-                        --sp;
-                        cur = stk.pop(sp);
-                    } else {
-                        cur = RT_IDLE;
-                        dirty = true;
                     }
+                    if (!(ls || rs)) {
+                        nxt = RT_DONE;
+                        if (sp > 0) {
+                            --sp;
+                            nxt = stk.pop(sp);
+                        }
+                    }
+                    cur = nxt;
                 }
             }
         }
         // ---- one triangle test for the lanes standing on a leaf, once enough of them wait there or no lane
         // has an inner node left
-        const bool at_leaf = cur < 0 && cur != RT_IDLE;
+        const bool at_leaf = cur < 0 && cur > RT_DONE;
         const int n_leaf = __popcll(__ballot(at_leaf));
         if (n_leaf >= leaf_min || (n_leaf > 0 && __ballot(cur >= 0) == 0ull)) {
             RT_PROBE_ADD(4, 1); RT_PROBE_ADD(5, n_leaf);
@@ -438,17 +443,15 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                         if (any_ray) finished = true;
                     }
                 }
+                cur = RT_DONE;
                 if (!finished && sp > 0) {
                     --sp;
                     cur = stk.pop(sp);
-                } else {
-                    cur = RT_IDLE;
-                    dirty = true;
                 }
             }
         }
     }
-    if (dirty) done(item, h);
+    if (cur == RT_DONE) done(item, h);
 }
 
 // Closest hit over a ray set (the batch form of BVH::intersect).  rays: 6

@@ -12,10 +12,11 @@ for r in rows:
     name = r["Kernel_Name"].split("(")[0].replace("void rt::", "").replace("rt::", "")
     ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 ev.sort()
-# passes start at k_generate
-starts = [i for i, e in enumerate(ev) if e[2].startswith("k_generate")]
-starts = starts[-passes:]
-segs = [ev[a:b] for a, b in zip(starts, starts[1:] + [len(ev)])]
+# a batch ends with k_film
+ends = [i + 1 for i, e in enumerate(ev) if e[2].startswith("k_film")]
+bounds = [0] + ends
+segs = [ev[a:b] for a, b in zip(bounds, bounds[1:])][-passes:]
+segs = [[e for e in seg if e[2].startswith("k_")] for seg in segs]
 agg = defaultdict(list)
 for seg in segs:
     cnt = defaultdict(int)
