@@ -256,6 +256,34 @@ int rt_lbvh_host(const float* pos, uint32_t pos_stride, const uint32_t* indices,
 /* Morton code of src/scene/BVH.cpp:189-212 for a point of the unit cube. */
 uint32_t rt_morton3d(float x, float y, float z);
 
+/* ---- several GPUs of one node driven by ONE process (the C++ host of the reference is a single process:
+ * src/app/App.cpp:40 makes one integrator).  Replaces the tile pool of Integrator::update
+ * (src/cpu/Integrator.cpp:33-49: 16 threads pulling 64x64 tiles) by n_devices GPUs, device i taking the tiles
+ * t % n_devices == i, and Integrator::sync (src/cpu/Integrator.cpp:21-24) by a gather of the devices' tile slabs:
+ * one RCCL communicator per device (ncclCommInitAll), one grouped ncclAllGather over xGMI, one scatter kernel on
+ * the first device.  The scene is replicated; params->device, rank and world are ignored (set per device).
+ * Every context renders on a host thread of its own inside rt_node_render.  RCCL is loaded at run time
+ * (librccl.so.1, or the path in RT_RCCL_LIB); RT_ERR_NO_DEVICE if it cannot be. */
+typedef struct rt_node rt_node;
+int rt_node_create(const rt_scene_desc* scene, const rt_params* params, const int32_t* devices, int32_t n_devices, rt_node** out);
+void rt_node_destroy(rt_node* node);
+/* Error text of the last failed call on node (node may be null for rt_node_create). */
+const char* rt_node_last_error(const rt_node* node);
+int rt_node_device_count(const rt_node* node);
+/* The context of device i (for rt_get_stats and the trace entry points); owned by the node. */
+rt_ctx* rt_node_context(rt_node* node, int32_t i);
+int rt_node_set_camera(rt_node* node, const float pos[3], const float right[3], const float up[3], const float forward[3]);
+int rt_node_reset_accumulation(rt_node* node);
+/* n_passes calls of Integrator::update over the whole film, every device tracing its own tiles. */
+int rt_node_render(rt_node* node, uint32_t n_passes);
+/* Gathers the film on the first device; *d_film_out = width*height*4 floats of device memory owned by the node
+ * (row-major, y = 0 at the top), valid until the next gather. */
+int rt_node_gather_film(rt_node* node, const float** d_film_out);
+/* rt_node_gather_film + copy to host: the whole film, width*height*4 floats. */
+int rt_node_read_film(rt_node* node, float* rgba_out);
+/* Device time of the last all-gather (HIP events on the first device's stream). */
+float rt_node_last_gather_ms(const rt_node* node);
+
 int rt_get_stats(rt_ctx* ctx, rt_stats* out);
 /* rt_stats.last_trace_ms without the device round trip of rt_get_stats. */
 float rt_last_trace_ms(const rt_ctx* ctx);

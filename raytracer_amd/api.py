@@ -77,6 +77,8 @@ EXPORTS = [
     "rt_trace_occluded", "rt_trace_closest_dev", "rt_trace_occluded_dev", "rt_get_bvh", "rt_get_stats",
     "rt_synchronize", "rt_version", "rt_lbvh_host", "rt_morton3d", "rt_last_trace_ms", "rt_slab_floats", "rt_pack_slab",
     "rt_read_primary_duv", "rt_trace_occluded_bounded", "rt_read_last_bounce_rays", "rt_trace_closest_noalloc",
+    "rt_node_create", "rt_node_destroy", "rt_node_last_error", "rt_node_device_count", "rt_node_context", "rt_node_set_camera",
+    "rt_node_reset_accumulation", "rt_node_render", "rt_node_gather_film", "rt_node_read_film", "rt_node_last_gather_ms",
 ]
 
 
@@ -126,8 +128,24 @@ def load_library():
     lib.rt_version.restype = C.c_char_p
     lib.rt_lbvh_host.argtypes = [fp, C.c_uint32, up, C.c_uint32, ip, ip, fp, ip, ip, ip, ip, ip]
     lib.rt_morton3d.argtypes = [C.c_float, C.c_float, C.c_float]
+    lib.rt_node_create.argtypes = [C.POINTER(rt_scene_desc), C.POINTER(rt_params), ip, C.c_int32, C.POINTER(vp)]
+    lib.rt_node_destroy.argtypes = [vp]
+    lib.rt_node_destroy.restype = None
+    lib.rt_node_last_error.argtypes = [vp]
+    lib.rt_node_last_error.restype = C.c_char_p
+    lib.rt_node_device_count.argtypes = [vp]
+    lib.rt_node_context.argtypes = [vp, C.c_int32]
+    lib.rt_node_context.restype = vp
+    lib.rt_node_set_camera.argtypes = [vp, fp, fp, fp, fp]
+    lib.rt_node_reset_accumulation.argtypes = [vp]
+    lib.rt_node_render.argtypes = [vp, C.c_uint32]
+    lib.rt_node_gather_film.argtypes = [vp, C.POINTER(vp)]
+    lib.rt_node_read_film.argtypes = [vp, fp]
+    lib.rt_node_last_gather_ms.argtypes = [vp]
+    lib.rt_node_last_gather_ms.restype = C.c_float
     for name in EXPORTS:
-        if name not in ("rt_destroy", "rt_last_error", "rt_version", "rt_morton3d", "rt_last_trace_ms", "rt_slab_floats"):
+        if name not in ("rt_destroy", "rt_last_error", "rt_version", "rt_morton3d", "rt_last_trace_ms", "rt_slab_floats",
+                        "rt_node_destroy", "rt_node_last_error", "rt_node_context", "rt_node_last_gather_ms"):
             getattr(lib, name).restype = C.c_int
     lib.rt_morton3d.restype = C.c_uint32
     lib.rt_slab_floats.restype = C.c_uint64
@@ -147,6 +165,52 @@ def _iptr(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_int32))
 
 
+def _scene_desc(s: Scene, use_frame: bool = True):
+    """rt_scene_desc over the arrays of a Scene, plus the objects that must outlive the call."""
+    keep = [s.pos, s.normal, s.uv, s.tangent, s.binormal, s.indices, s.tri_model]
+    mats = (rt_material * s.n_models)()
+    for m in range(s.n_models):
+        mats[m].diffuse_color[:] = [float(x) for x in s.materials[m, :3]]
+        mats[m].roughness = float(s.materials[m, 3])
+        mats[m].texture = int(s.material_texture[m])
+        mats[m].glossy = int(s.material_glossy[m])
+    textures = (rt_texture * max(1, len(s.textures)))()
+    for i, t in enumerate(s.textures):
+        t = np.ascontiguousarray(t, np.uint8)
+        keep.append(t)
+        textures[i].height, textures[i].width = t.shape[0], t.shape[1]
+        textures[i].rgba8 = t.ctypes.data_as(C.POINTER(C.c_uint8))
+    lights = (rt_light * max(1, len(s.lights)))()
+    for i, l in enumerate(s.lights):
+        lights[i].type = l.type
+        lights[i].pos[:] = [float(x) for x in l.pos]
+        lights[i].intensity[:] = [float(x) for x in l.intensity]
+        if l.tri is not None:
+            for name, pt in zip(("p0", "p1", "p2"), l.tri):
+                getattr(lights[i], name)[:] = [float(x) for x in pt]
+        if l.type == LIGHT_ENV:
+            env = np.ascontiguousarray(l.env, np.float32)
+            keep.append(env)
+            lights[i].env_rgba = _fptr(env)
+            lights[i].env_h, lights[i].env_w = env.shape[0], env.shape[1]
+    d = rt_scene_desc()
+    d.n_vertices = s.pos.shape[0]
+    d.pos, d.pos_stride = _fptr(s.pos), 12
+    d.normal, d.normal_stride = _fptr(s.normal), 12
+    d.uv, d.uv_stride = _fptr(s.uv), 8
+    if use_frame:
+        d.tangent, d.tangent_stride = _fptr(s.tangent), 12
+        d.binormal, d.binormal_stride = _fptr(s.binormal), 12
+    d.n_indices = s.indices.size
+    d.indices = s.indices.ctypes.data_as(C.POINTER(C.c_uint32))
+    d.tri_model = _iptr(s.tri_model)
+    d.n_models, d.materials = s.n_models, mats
+    d.n_lights, d.lights = len(s.lights), lights
+    d.n_textures, d.textures = len(s.textures), textures
+    keep += [mats, textures, lights]
+    return d, keep
+
+
 class Context:
     """One rt_ctx: a scene resident on one MI355X plus this rank's share of the film."""
 
@@ -155,47 +219,7 @@ class Context:
         self._lib = load_library()
         self._h = C.c_void_p()
         self.width, self.height, self.world, self.rank, self.tile_size = width, height, world, rank, tile_size
-        s = scene
-        self._keep = [s.pos, s.normal, s.uv, s.tangent, s.binormal, s.indices, s.tri_model]
-        mats = (rt_material * s.n_models)()
-        for m in range(s.n_models):
-            mats[m].diffuse_color[:] = [float(x) for x in s.materials[m, :3]]
-            mats[m].roughness = float(s.materials[m, 3])
-            mats[m].texture = int(s.material_texture[m])
-            mats[m].glossy = int(s.material_glossy[m])
-        textures = (rt_texture * max(1, len(s.textures)))()
-        for i, t in enumerate(s.textures):
-            t = np.ascontiguousarray(t, np.uint8)
-            self._keep.append(t)
-            textures[i].height, textures[i].width = t.shape[0], t.shape[1]
-            textures[i].rgba8 = t.ctypes.data_as(C.POINTER(C.c_uint8))
-        lights = (rt_light * max(1, len(s.lights)))()
-        for i, l in enumerate(s.lights):
-            lights[i].type = l.type
-            lights[i].pos[:] = [float(x) for x in l.pos]
-            lights[i].intensity[:] = [float(x) for x in l.intensity]
-            if l.tri is not None:
-                for name, pt in zip(("p0", "p1", "p2"), l.tri):
-                    getattr(lights[i], name)[:] = [float(x) for x in pt]
-            if l.type == LIGHT_ENV:
-                env = np.ascontiguousarray(l.env, np.float32)
-                self._keep.append(env)
-                lights[i].env_rgba = _fptr(env)
-                lights[i].env_h, lights[i].env_w = env.shape[0], env.shape[1]
-        d = rt_scene_desc()
-        d.n_vertices = s.pos.shape[0]
-        d.pos, d.pos_stride = _fptr(s.pos), 12
-        d.normal, d.normal_stride = _fptr(s.normal), 12
-        d.uv, d.uv_stride = _fptr(s.uv), 8
-        if use_frame:
-            d.tangent, d.tangent_stride = _fptr(s.tangent), 12
-            d.binormal, d.binormal_stride = _fptr(s.binormal), 12
-        d.n_indices = s.indices.size
-        d.indices = s.indices.ctypes.data_as(C.POINTER(C.c_uint32))
-        d.tri_model = _iptr(s.tri_model)
-        d.n_models, d.materials = s.n_models, mats
-        d.n_lights, d.lights = len(s.lights), lights
-        d.n_textures, d.textures = len(s.textures), textures
+        d, self._keep = _scene_desc(scene, use_frame)
         p = rt_params(width, height, max_depth, tile_size, seed, device, rank, world, RT_FLAG_HOST_BVH if host_bvh else 0, batch)
         rc = self._lib.rt_create(C.byref(d), C.byref(p), C.byref(self._h))
         if rc != 0:
@@ -315,6 +339,70 @@ class Context:
 
     def synchronize(self):
         self._check(self._lib.rt_synchronize(self._h))
+
+
+class Node:
+    """One rt_node: several GPUs of a node driven by this process, one film sharded over them by interleaved tiles
+    and gathered with RCCL at read-out (rt_node_* of include/rt_hip.h)."""
+
+    def __init__(self, scene: Scene, width: int, height: int, devices, max_depth: int = 4, seed: int = 0, tile_size: int = 64,
+                 use_frame: bool = True, batch: int = 0):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.width, self.height, self.tile_size, self.devices = width, height, tile_size, list(devices)
+        d, self._keep = _scene_desc(scene, use_frame)
+        p = rt_params(width, height, max_depth, tile_size, seed, 0, 0, 1, 0, batch)
+        devs = (C.c_int32 * len(self.devices))(*self.devices)
+        rc = self._lib.rt_node_create(C.byref(d), C.byref(p), devs, len(self.devices), C.byref(self._h))
+        if rc != 0:
+            raise RtError(rc, self._lib.rt_node_last_error(None).decode())
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise RtError(rc, self._lib.rt_node_last_error(self._h).decode())
+
+    def close(self):
+        if self._h:
+            self._lib.rt_node_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_camera(self, cam: Camera):
+        a = [np.ascontiguousarray(v, np.float32) for v in (cam.pos, cam.right, cam.up, cam.forward)]
+        self._check(self._lib.rt_node_set_camera(self._h, *[_fptr(v) for v in a]))
+
+    def reset_accumulation(self):
+        self._check(self._lib.rt_node_reset_accumulation(self._h))
+
+    def render(self, n_passes: int = 1):
+        self._check(self._lib.rt_node_render(self._h, n_passes))
+
+    def read_film(self) -> np.ndarray:
+        out = np.empty((self.height, self.width, 4), np.float32)
+        self._check(self._lib.rt_node_read_film(self._h, _fptr(out)))
+        return out
+
+    def gather_film_device(self) -> int:
+        """Device pointer (first device) of the gathered width*height*4 film."""
+        ptr = C.c_void_p()
+        self._check(self._lib.rt_node_gather_film(self._h, C.byref(ptr)))
+        return int(ptr.value or 0)
+
+    def last_gather_ms(self) -> float:
+        return float(self._lib.rt_node_last_gather_ms(self._h))
+
+    def device_stats(self, i: int) -> dict:
+        st = rt_stats()
+        h = self._lib.rt_node_context(self._h, i)
+        rc = self._lib.rt_get_stats(h, C.byref(st))
+        if rc != 0:
+            raise RtError(rc, self._lib.rt_last_error(h).decode())
+        return {k: getattr(st, k) for k, _ in rt_stats._fields_}
 
 
 def unpack_slabs(width: int, height: int, tile_size: int, world: int, slabs: np.ndarray, per_rank: int) -> np.ndarray:

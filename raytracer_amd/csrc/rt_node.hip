@@ -1,0 +1,295 @@
+// One process driving several GPUs of a node (declared in include/rt_hip.h, rt_node_*): the scene is replicated
+// on every device, the film is sharded by interleaved tiles (rank i of n on device i: the GPU form of the
+// reference's tile pool, src/cpu/Integrator.cpp:33-49), every device renders its tiles on a host thread of its
+// own, and at read-out the tile slabs are all-gathered with RCCL (one communicator per device, ncclCommInitAll,
+// one grouped ncclAllGather) and scattered into the film on the first device.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1): the library then carries no link-time dependency on a
+// particular RCCL build, and a process that already holds one (PyTorch ships its own) shares it.
+#include <hip/hip_runtime.h>
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rt_hip.h"
+
+namespace {
+
+typedef struct ncclComm* ncclComm_t;
+typedef int ncclResult_t;
+constexpr int kNcclFloat = 7;   // ncclFloat32 of rccl.h
+
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+bool load_rccl(Rccl& r, std::string& err) {
+    const char* names[] = {getenv("RT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (r.handle) break;
+    }
+    if (!r.handle) {
+        err = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "not found");
+        return false;
+    }
+    auto sym = [&](const char* s) { return dlsym(r.handle, s); };
+    r.CommInitAll = reinterpret_cast<decltype(r.CommInitAll)>(sym("ncclCommInitAll"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(sym("ncclCommDestroy"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
+    if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.AllGather || !r.GetErrorString) {
+        err = "the RCCL library lacks an expected entry point";
+        return false;
+    }
+    return true;
+}
+
+thread_local std::string g_node_create_error;
+
+}  // namespace
+
+struct rt_node {
+    int n = 0;
+    int width = 0, height = 0, tile = 64;
+    std::vector<int> devices;
+    std::vector<rt_ctx*> ctx;
+    std::vector<hipStream_t> streams;     // one per device, for the slab copy and the gather
+    std::vector<float*> d_local;          // this device's slab, padded to per_rank floats
+    std::vector<float*> d_gathered;       // n * per_rank floats per device
+    float* d_film = nullptr;              // width * height * 4 floats on devices[0]
+    uint64_t per_rank = 0;                // floats
+    Rccl rccl;
+    std::vector<ncclComm_t> comms;
+    std::string err;
+    float last_gather_ms = 0.f;
+};
+
+namespace {
+
+#define NODE_HIP(nd, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            (nd)->err = std::string(#call) + " failed: " + hipGetErrorString(e_);                       \
+            return RT_ERR_HIP;                                                                          \
+        }                                                                                               \
+    } while (0)
+
+#define NODE_NCCL(nd, call)                                                                             \
+    do {                                                                                                \
+        ncclResult_t r_ = (call);                                                                       \
+        if (r_ != 0) {                                                                                  \
+            (nd)->err = std::string(#call) + " failed: " + (nd)->rccl.GetErrorString(r_);               \
+            return RT_ERR_HIP;                                                                          \
+        }                                                                                               \
+    } while (0)
+
+// Runs fn(i) for every device on a thread of its own and returns the first non-zero status.
+template <typename F>
+int for_each_device(rt_node* nd, F fn) {
+    std::vector<int> rc(nd->n, RT_OK);
+    if (nd->n == 1) {
+        rc[0] = fn(0);
+    } else {
+        std::vector<std::thread> th;
+        th.reserve(nd->n);
+        for (int i = 0; i < nd->n; ++i) th.emplace_back([&, i]() { rc[i] = fn(i); });
+        for (auto& t : th) t.join();
+    }
+    for (int i = 0; i < nd->n; ++i)
+        if (rc[i] != RT_OK) {
+            nd->err = std::string("device ") + std::to_string(nd->devices[i]) + ": " + rt_last_error(nd->ctx[i]);
+            return rc[i];
+        }
+    return RT_OK;
+}
+
+int node_create_impl(rt_node* nd, const rt_scene_desc* scene, const rt_params* params, const int32_t* devices, int32_t n) {
+    nd->n = n;
+    nd->width = params->width;
+    nd->height = params->height;
+    nd->tile = params->tile_size > 0 ? params->tile_size : 64;
+    nd->devices.assign(devices, devices + n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < i; ++j)
+            if (devices[i] == devices[j]) {
+                nd->err = "a device is listed twice";
+                return RT_ERR_ARG;
+            }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        nd->err = std::string("device ") + std::to_string(devices[0]) + ": no HIP device available";
+        return RT_ERR_NO_DEVICE;
+    }
+    for (int i = 0; i < n; ++i)
+        if (devices[i] < 0 || devices[i] >= ndev) {
+            nd->err = std::string("device ") + std::to_string(devices[i]) + ": ordinal out of range";
+            return RT_ERR_ARG;
+        }
+    nd->ctx.assign(n, nullptr);
+    // contexts one after the other: rt_create reports its error text per calling thread
+    for (int i = 0; i < n; ++i) {
+        rt_params p = *params;
+        p.device = devices[i];
+        p.rank = i;
+        p.world = n;
+        int r = rt_create(scene, &p, &nd->ctx[i]);
+        if (r != RT_OK) {
+            nd->err = std::string("device ") + std::to_string(devices[i]) + ": " + rt_last_error(nullptr);
+            return r;
+        }
+    }
+    nd->per_rank = 0;
+    for (int i = 0; i < n; ++i) nd->per_rank = std::max<uint64_t>(nd->per_rank, rt_slab_floats(nd->width, nd->height, nd->tile, i, n));
+    if (nd->per_rank == 0) nd->per_rank = 4;
+    nd->streams.assign(n, nullptr);
+    nd->d_local.assign(n, nullptr);
+    nd->d_gathered.assign(n, nullptr);
+    for (int i = 0; i < n; ++i) {
+        NODE_HIP(nd, hipSetDevice(devices[i]));
+        NODE_HIP(nd, hipStreamCreateWithFlags(&nd->streams[i], hipStreamNonBlocking));
+        NODE_HIP(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_local[i]), nd->per_rank * sizeof(float)));
+        NODE_HIP(nd, hipMemset(nd->d_local[i], 0, nd->per_rank * sizeof(float)));   // the padding behind a short slab stays zero
+        NODE_HIP(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_gathered[i]), (size_t)n * nd->per_rank * sizeof(float)));
+    }
+    NODE_HIP(nd, hipSetDevice(devices[0]));
+    NODE_HIP(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_film), (size_t)nd->width * nd->height * 4 * sizeof(float)));
+    if (!load_rccl(nd->rccl, nd->err)) return RT_ERR_NO_DEVICE;
+    nd->comms.assign(n, nullptr);
+    NODE_NCCL(nd, nd->rccl.CommInitAll(nd->comms.data(), n, nd->devices.data()));
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_node_last_error(const rt_node* nd) { return nd ? nd->err.c_str() : g_node_create_error.c_str(); }
+
+void rt_node_destroy(rt_node* nd) {
+    if (!nd) return;
+    for (int i = 0; i < nd->n; ++i) {
+        if (i >= (int)nd->ctx.size() || !nd->ctx[i]) continue;   // create stopped before this device
+        (void)hipSetDevice(nd->devices[i]);
+        if (i < (int)nd->comms.size() && nd->comms[i]) (void)nd->rccl.CommDestroy(nd->comms[i]);
+        if (i < (int)nd->streams.size() && nd->streams[i]) { (void)hipStreamSynchronize(nd->streams[i]); (void)hipStreamDestroy(nd->streams[i]); }
+        if (i < (int)nd->d_local.size() && nd->d_local[i]) (void)hipFree(nd->d_local[i]);
+        if (i < (int)nd->d_gathered.size() && nd->d_gathered[i]) (void)hipFree(nd->d_gathered[i]);
+        if (i < (int)nd->ctx.size() && nd->ctx[i]) rt_destroy(nd->ctx[i]);
+    }
+    if (nd->d_film) { (void)hipSetDevice(nd->devices[0]); (void)hipFree(nd->d_film); }
+    (void)hipGetLastError();   // a failed create must not leave a stale error behind for the next HIP call to report
+    delete nd;
+}
+
+int rt_node_create(const rt_scene_desc* scene, const rt_params* params, const int32_t* devices, int32_t n_devices, rt_node** out) {
+    if (!scene || !params || !devices || !out || n_devices < 1 || n_devices > 64) {
+        g_node_create_error = "rt_node_create: null argument or device count outside 1..64";
+        return RT_ERR_ARG;
+    }
+    *out = nullptr;
+    rt_node* nd = new rt_node();
+    int r = node_create_impl(nd, scene, params, devices, n_devices);
+    if (r != RT_OK) {
+        g_node_create_error = nd->err;
+        rt_node_destroy(nd);
+        return r;
+    }
+    *out = nd;
+    return RT_OK;
+}
+
+int rt_node_device_count(const rt_node* nd) { return nd ? nd->n : 0; }
+
+rt_ctx* rt_node_context(rt_node* nd, int32_t i) { return (nd && i >= 0 && i < nd->n) ? nd->ctx[i] : nullptr; }
+
+int rt_node_set_camera(rt_node* nd, const float pos[3], const float right[3], const float up[3], const float forward[3]) {
+    if (!nd) return RT_ERR_ARG;
+    for (int i = 0; i < nd->n; ++i) {
+        int r = rt_set_camera(nd->ctx[i], pos, right, up, forward);
+        if (r != RT_OK) { nd->err = rt_last_error(nd->ctx[i]); return r; }
+    }
+    return RT_OK;
+}
+
+int rt_node_reset_accumulation(rt_node* nd) {
+    if (!nd) return RT_ERR_ARG;
+    for (int i = 0; i < nd->n; ++i) rt_reset_accumulation(nd->ctx[i]);
+    return RT_OK;
+}
+
+int rt_node_render(rt_node* nd, uint32_t n_passes) {
+    if (!nd) return RT_ERR_ARG;
+    return for_each_device(nd, [&](int i) { return rt_render(nd->ctx[i], n_passes); });
+}
+
+int rt_node_gather_film(rt_node* nd, const float** d_film_out) {
+    if (!nd) return RT_ERR_ARG;
+    const int n = nd->n;
+    // every device: its slab into the padded send buffer (rt_copy_film_slab waits for the device's renders first)
+    int r = for_each_device(nd, [&](int i) {
+        const uint64_t nf = rt_slab_floats(nd->width, nd->height, nd->tile, i, n);
+        return nf ? rt_copy_film_slab(nd->ctx[i], nd->d_local[i], nf) : (int)RT_OK;
+    });
+    if (r != RT_OK) return r;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    NODE_HIP(nd, hipSetDevice(nd->devices[0]));
+    NODE_HIP(nd, hipEventCreate(&e0));
+    NODE_HIP(nd, hipEventCreate(&e1));
+    NODE_HIP(nd, hipEventRecord(e0, nd->streams[0]));
+    NODE_NCCL(nd, nd->rccl.GroupStart());
+    for (int i = 0; i < n; ++i) {
+        ncclResult_t g = nd->rccl.AllGather(nd->d_local[i], nd->d_gathered[i], nd->per_rank, kNcclFloat, nd->comms[i], nd->streams[i]);
+        if (g != 0) {
+            (void)nd->rccl.GroupEnd();
+            nd->err = std::string("ncclAllGather failed: ") + nd->rccl.GetErrorString(g);
+            return RT_ERR_HIP;
+        }
+    }
+    NODE_NCCL(nd, nd->rccl.GroupEnd());
+    for (int i = 0; i < n; ++i) {
+        NODE_HIP(nd, hipSetDevice(nd->devices[i]));
+        NODE_HIP(nd, hipStreamSynchronize(nd->streams[i]));
+    }
+    NODE_HIP(nd, hipSetDevice(nd->devices[0]));
+    NODE_HIP(nd, hipEventRecord(e1, nd->streams[0]));
+    NODE_HIP(nd, hipEventSynchronize(e1));
+    NODE_HIP(nd, hipEventElapsedTime(&nd->last_gather_ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    // the scatter runs on the first context's stream and returns when it is done
+    r = rt_unpack_slabs_dev(nd->ctx[0], n, nd->d_gathered[0], nd->per_rank, nd->d_film);
+    if (r != RT_OK) { nd->err = rt_last_error(nd->ctx[0]); return r; }
+    if (d_film_out) *d_film_out = nd->d_film;
+    return RT_OK;
+}
+
+int rt_node_read_film(rt_node* nd, float* rgba_out) {
+    if (!nd || !rgba_out) return RT_ERR_ARG;
+    int r = rt_node_gather_film(nd, nullptr);
+    if (r != RT_OK) return r;
+    NODE_HIP(nd, hipSetDevice(nd->devices[0]));
+    NODE_HIP(nd, hipMemcpy(rgba_out, nd->d_film, (size_t)nd->width * nd->height * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+float rt_node_last_gather_ms(const rt_node* nd) { return nd ? nd->last_gather_ms : 0.f; }
+
+}  // extern "C"

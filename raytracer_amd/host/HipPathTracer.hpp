@@ -32,17 +32,30 @@ class HipPathTracer {
     // a larger value makes every update() add that many passes, traced together as one wavefront.
     HipPathTracer(const rt_scene_desc& scene, int width, int height, int max_depth = 4, uint64_t seed = 0, int device = 0,
                   uint32_t passes_per_update = 1)
+        : HipPathTracer(scene, width, height, std::vector<int32_t>{device}, max_depth, seed, passes_per_update) {}
+    // Several GPUs of the node: the 64x64 tiles that the reference deals to its 16 threads
+    // (src/cpu/Integrator.cpp:33-49) are dealt to the devices instead (tile t to devices[t % n]); sync() receives the
+    // film gathered over RCCL.  One device keeps to the single-context entry points.
+    // (use_node = true takes the multi-device entry points for a single device too.)
+    HipPathTracer(const rt_scene_desc& scene, int width, int height, const std::vector<int32_t>& devices, int max_depth = 4,
+                  uint64_t seed = 0, uint32_t passes_per_update = 1, bool use_node = false)
         : _width(width), _height(height), _passes(passes_per_update ? passes_per_update : 1) {
+        if (devices.empty()) throw std::runtime_error("HipPathTracer: no device given");
         rt_params p{};
         p.width = width; p.height = height; p.max_depth = max_depth; p.tile_size = 64;
-        p.seed = seed; p.device = device; p.rank = 0; p.world = 1;
+        p.seed = seed; p.device = devices[0]; p.rank = 0; p.world = 1;
         p.batch = _passes;   // path state sized for what one update() traces
-        if (rt_create(&scene, &p, &_ctx) != RT_OK) throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
+        if (devices.size() == 1 && !use_node) {
+            if (rt_create(&scene, &p, &_ctx) != RT_OK) throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
+        } else if (rt_node_create(&scene, &p, devices.data(), (int32_t)devices.size(), &_node) != RT_OK) {
+            throw std::runtime_error(std::string("rt_node_create: ") + rt_node_last_error(nullptr));
+        }
         _frame.assign((size_t)width * height * 4, 0.f);
     }
     ~HipPathTracer() {
         finish();
-        rt_destroy(_ctx);
+        if (_node) rt_node_destroy(_node);
+        else rt_destroy(_ctx);
     }
     HipPathTracer(const HipPathTracer&) = delete;
     HipPathTracer& operator=(const HipPathTracer&) = delete;
@@ -90,14 +103,18 @@ class HipPathTracer {
     void sync(float* rgba_dst) { std::memcpy(rgba_dst, _frame.data(), _frame.size() * sizeof(float)); }
 
     uint64_t frames() const { return _frames; }
-    rt_ctx* context() { return _ctx; }
+    rt_ctx* context() { return _node ? rt_node_context(_node, 0) : _ctx; }
+    int deviceCount() const { return _node ? rt_node_device_count(_node) : 1; }
 
    protected:
     // src/cpu/Integrator.cpp:26-67 with the tile pool replaced by one rt_render pass
     void update() {
-        if (rt_set_camera(_ctx, _pos, _right, _up, _forward) != RT_OK || rt_render(_ctx, _passes) != RT_OK ||
-            rt_read_film(_ctx, _frame.data()) != RT_OK) {
-            _error = rt_last_error(_ctx);
+        const bool ok = _node ? (rt_node_set_camera(_node, _pos, _right, _up, _forward) == RT_OK && rt_node_render(_node, _passes) == RT_OK &&
+                                 rt_node_read_film(_node, _frame.data()) == RT_OK)
+                              : (rt_set_camera(_ctx, _pos, _right, _up, _forward) == RT_OK && rt_render(_ctx, _passes) == RT_OK &&
+                                 rt_read_film(_ctx, _frame.data()) == RT_OK);
+        if (!ok) {
+            _error = _node ? rt_node_last_error(_node) : rt_last_error(_ctx);
             _failed = true;
             _isRun = false;
             return;
@@ -105,7 +122,8 @@ class HipPathTracer {
         _frames += _passes;
     }
 
-    rt_ctx* _ctx = nullptr;
+    rt_ctx* _ctx = nullptr;     // one device
+    rt_node* _node = nullptr;   // several devices
     int _width, _height;
     uint32_t _passes = 1;
     float _pos[3]{}, _right[3]{}, _forward[3]{}, _up[3]{};

@@ -1,6 +1,7 @@
 // Drives HipPathTracer the way the reference app drives its integrator
 // (src/app/App.cpp:92-93,113-121) on a scene read from a flat binary dump.
-// usage: demo_host <scene.bin> <width> <height> <frames> <out_film.f32>
+// usage: demo_host <scene.bin> <width> <height> <frames> <out_film.f32> [devices, e.g. 0,1,2,3] [node]
+// (`node` drives a single device through the multi-device entry points as well)
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -51,8 +52,14 @@ int main(int argc, char** argv) {
     sd.n_models = hdr[2]; sd.materials = materials.data();
     sd.n_lights = hdr[3]; sd.lights = lights.data();
     const int W = atoi(argv[2]), H = atoi(argv[3]), frames = atoi(argv[4]);
+    std::vector<int32_t> devices;
+    for (const char* p = argc > 6 ? argv[6] : "0"; *p;) {
+        devices.push_back((int32_t)strtol(p, const_cast<char**>(&p), 10));
+        if (*p == ',') ++p;
+    }
+    const bool use_node = argc > 7 && std::string(argv[7]) == "node";
     try {
-        HipPathTracer pt(sd, W, H);
+        HipPathTracer pt(sd, W, H, devices, 4, 0, 1, use_node);
         std::vector<float> film((size_t)W * H * 4);
         pt.nextFrame(&cam[0], &cam[3], &cam[6]);
         pt.run();
@@ -69,7 +76,7 @@ int main(int argc, char** argv) {
         pt.finish();
         std::ofstream o(argv[5], std::ios::binary);
         o.write(reinterpret_cast<const char*>(film.data()), film.size() * sizeof(float));
-        printf("frames %llu\n", (unsigned long long)pt.frames());
+        printf("frames %llu devices %d\n", (unsigned long long)pt.frames(), pt.deviceCount());
     } catch (const std::exception& e) {
         fprintf(stderr, "error: %s\n", e.what());
         return 1;

@@ -54,6 +54,46 @@ def test_cpp_host_adapter_matches_direct_render(cornell):
     assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
 
 
+def test_cpp_host_adapter_through_the_multi_device_entry_points(cornell):
+    """The same program with a device list, driving rt_node_* (one GPU here: the tile deal, the RCCL all-gather
+    and the scatter all run, with a world of one)."""
+    W, H, frames = 200, 136, 2
+    with tempfile.TemporaryDirectory() as td:
+        sp, fp = os.path.join(td, "scene.bin"), os.path.join(td, "film.f32")
+        _dump(cornell, sp)
+        out = subprocess.run([DEMO, sp, str(W), str(H), str(frames), fp, "0", "node"], capture_output=True, text=True, timeout=200)
+        assert out.returncode == 0, out.stderr
+        assert f"frames {frames} devices 1" in out.stdout
+        film = np.fromfile(fp, np.float32).reshape(H, W, 4)
+    ref = _direct(cornell, W, H, frames)
+    assert np.array_equal(film.view(np.uint32), ref.view(np.uint32))
+
+
+def test_node_api_single_device(cornell_env):
+    from raytracer_amd import Node, api
+    W, H = 150, 90
+    node = Node(cornell_env, W, H, [0], max_depth=3, seed=5, tile_size=32, batch=2)
+    node.set_camera(cornell_env.camera)
+    node.render(3)
+    film = node.read_film()
+    assert node.gather_film_device() != 0 and node.last_gather_ms() > 0
+    st = node.device_stats(0)
+    assert st["passes"] == 3 and st["n_local_pixels"] == W * H
+    node.reset_accumulation()
+    node.render(3)
+    assert np.array_equal(node.read_film().view(np.uint32), film.view(np.uint32))
+    node.close()
+    ctx = Context(cornell_env, W, H, max_depth=3, seed=5, tile_size=32)
+    ctx.set_camera(cornell_env.camera)
+    ctx.render(3)
+    assert np.array_equal(film.view(np.uint32), ctx.read_film().view(np.uint32))
+    ctx.close()
+    with pytest.raises(api.RtError):
+        Node(cornell_env, W, H, [0, 0])          # a device twice
+    with pytest.raises(api.RtError):
+        Node(cornell_env, W, H, [99])
+
+
 def test_python_integrator_mirror(cornell):
     W, H = 64, 48
     pt = HipPathTracer(cornell, W, H)

@@ -46,6 +46,25 @@ def test_create_without_gpu_fails_loudly(cornell):
     assert e.value.code == -3
 
 
+def test_node_create_argument_errors(cornell):
+    lib = api.load_library()
+    h = C.c_void_p()
+    d, p = api.rt_scene_desc(), api.rt_params()
+    devs = (C.c_int32 * 2)(0, 0)
+    assert lib.rt_node_create(None, None, devs, 1, C.byref(h)) == -1
+    assert lib.rt_node_create(C.byref(d), C.byref(p), devs, 0, C.byref(h)) == -1
+    assert lib.rt_node_create(C.byref(d), C.byref(p), devs, 2, C.byref(h)) == -1 and b"twice" in lib.rt_node_last_error(None)
+    assert not h.value
+    assert lib.rt_node_render(None, 1) == -1 and lib.rt_node_read_film(None, None) == -1
+    assert lib.rt_node_device_count(None) == 0 and not lib.rt_node_context(None, 0)
+    lib.rt_node_destroy(None)
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(api.RtError) as e:
+            api.Node(cornell, 32, 32, [0])
+        assert e.value.code == -3 and "device 0" in str(e.value)
+
+
 def test_null_context_calls_return_arg_error():
     lib = api.load_library()
     assert lib.rt_render(None, 1) == -1
@@ -233,6 +252,14 @@ const char* rt_last_error(const rt_ctx*) { return "forced failure"; }
 int rt_set_camera(rt_ctx*, const float*, const float*, const float*, const float*) { return 0; }
 int rt_render(rt_ctx*, uint32_t) { return ++g_calls >= 2 ? RT_ERR_LIMIT : RT_OK; }
 int rt_read_film(rt_ctx*, float*) { return 0; }
+int rt_node_create(const rt_scene_desc*, const rt_params*, const int32_t*, int32_t, rt_node**) { return RT_ERR_ARG; }
+void rt_node_destroy(rt_node*) {}
+const char* rt_node_last_error(const rt_node*) { return ""; }
+int rt_node_device_count(const rt_node*) { return 0; }
+rt_ctx* rt_node_context(rt_node*, int32_t) { return nullptr; }
+int rt_node_set_camera(rt_node*, const float*, const float*, const float*, const float*) { return 0; }
+int rt_node_render(rt_node*, uint32_t) { return 0; }
+int rt_node_read_film(rt_node*, float*) { return 0; }
 }
 static bool wait_finish(HipPathTracer& pt) {
     auto t0 = std::chrono::steady_clock::now();
