@@ -58,8 +58,8 @@ unsigned char* scratch_address(int device, hipError_t* e) {
 
 struct EnvTables {
     float4* img = nullptr;
-    float *cond_func = nullptr, *cond_cdf = nullptr, *cond_int = nullptr, *marg_cdf = nullptr;
-    int32_t *cond_guide = nullptr, *marg_guide = nullptr;
+    float4 *cond_pack = nullptr, *marg_pack = nullptr;
+    float* cond_int = nullptr;
 };
 
 }  // namespace
@@ -254,22 +254,35 @@ int build_env(rt_ctx* c, const rt_light& src, DevLight& dst, EnvTables& tab) {
     }
     for (int v = 0; v < W; ++v) cint[v] = build_cdf(&table[(size_t)v * H], H, &cdf[(size_t)v * (H + 1)]);
     float mint = build_cdf(cint.data(), W, mcdf.data());
-    std::vector<int32_t> cguide((size_t)W * (H + 1)), mguide(W + 1);
-    for (int v = 0; v < W; ++v) build_guide(&cdf[(size_t)v * (H + 1)], H, &cguide[(size_t)v * (H + 1)]);
-    build_guide(mcdf.data(), W, mguide.data());
+    // packed records (DistEntry layout of shade.h): cdf pair, function value and the guide bracket of bucket i
+    if (W > 65534 || H > 65534) {
+        c->err = "env image larger than 65534 in one direction";
+        return RT_ERR_LIMIT;
+    }
+    std::vector<int32_t> guide;
+    auto pack_rows = [&](const float* func, const float* cdfp, int n, float4* out) {
+        guide.resize(n + 1);
+        build_guide(cdfp, n, guide.data());
+        for (int i = 0; i <= n; ++i) {
+            const uint32_t lo = (uint32_t)guide[i > 0 ? i - 1 : 0], hi = (uint32_t)guide[i + 2 < n ? i + 2 : n];
+            const uint32_t bits = lo | (hi << 16);
+            float w;
+            memcpy(&w, &bits, 4);
+            out[i] = make_float4(cdfp[i], i < n ? cdfp[i + 1] : cdfp[i], i < n ? func[i] : 0.f, w);
+        }
+    };
+    std::vector<float4> cpack((size_t)W * (H + 1)), mpack(W + 1);
+    for (int v = 0; v < W; ++v) pack_rows(&table[(size_t)v * H], &cdf[(size_t)v * (H + 1)], H, &cpack[(size_t)v * (H + 1)]);
+    pack_rows(cint.data(), mcdf.data(), W, mpack.data());
     int r;
-    if ((r = dev_upload(c, &tab.cond_guide, cguide.data(), cguide.size()))) return r;
-    if ((r = dev_upload(c, &tab.marg_guide, mguide.data(), mguide.size()))) return r;
     if ((r = dev_upload(c, &tab.img, reinterpret_cast<const float4*>(src.env_rgba), (size_t)W * H))) return r;
-    if ((r = dev_upload(c, &tab.cond_func, table.data(), table.size()))) return r;
-    if ((r = dev_upload(c, &tab.cond_cdf, cdf.data(), cdf.size()))) return r;
+    if ((r = dev_upload(c, &tab.cond_pack, cpack.data(), cpack.size()))) return r;
+    if ((r = dev_upload(c, &tab.marg_pack, mpack.data(), mpack.size()))) return r;
     if ((r = dev_upload(c, &tab.cond_int, cint.data(), cint.size()))) return r;
-    if ((r = dev_upload(c, &tab.marg_cdf, mcdf.data(), mcdf.size()))) return r;
     dst.W = W; dst.H = H;
     dst.img = tab.img;
-    dst.cond_func = tab.cond_func; dst.cond_cdf = tab.cond_cdf; dst.cond_int = tab.cond_int;
-    dst.marg_cdf = tab.marg_cdf; dst.marg_int = mint;
-    dst.cond_guide = tab.cond_guide; dst.marg_guide = tab.marg_guide;
+    dst.cond_pack = tab.cond_pack; dst.cond_int = tab.cond_int;
+    dst.marg_pack = tab.marg_pack; dst.marg_int = mint;
     return RT_OK;
 }
 
@@ -729,6 +742,7 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         if ((r = dev_upload(c, &c->d_texels, texels.data(), texels.size()))) return r;
     }
     c->n_lights = (int)sd->n_lights;
+    c->ss.env_staged = -1;
     {
         std::vector<DevLight> lights(sd->n_lights);
         c->env.resize(sd->n_lights);
@@ -741,6 +755,7 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
             d.ix = s.intensity[0]; d.iy = s.intensity[1]; d.iz = s.intensity[2];
             if (s.type == RT_LIGHT_ENV) {
                 if ((r = build_env(c, s, d, c->env[l]))) return r;
+                if (c->ss.env_staged < 0 && s.env_w + 1 <= RT_MARG_LDS) c->ss.env_staged = (int32_t)l;
             } else if (s.type == RT_LIGHT_AREA) {
                 float e1[3], e2[3];
                 for (int k = 0; k < 3; ++k) {

@@ -25,14 +25,13 @@ struct DevLight {
     int32_t W, H;          // env image size
     const float4* img;     // env texels, row-major
     // Distribution2D built as EnvLight's ctor does (src/lights/EnvLight.cpp:16-25):
-    // W conditional rows of H entries each, marginal over the W rows.
-    const float* cond_func;  // [W][H]
-    const float* cond_cdf;   // [W][H+1]
-    const float* cond_int;   // [W] (also the marginal's func)
-    const float* marg_cdf;   // [W+1]
+    // W conditional rows of H entries each, marginal over the W rows.  Each Distribution1D of n entries is
+    // stored as n + 1 records (DistEntry below), so that the guided search reads its bracket of the guide
+    // table with one 4-byte load and the interval's CDF pair and function value with one 16-byte load.
+    const float4* cond_pack; // [W][H+1]
+    const float* cond_int;   // [W]: funcInt of each conditional row
+    const float4* marg_pack; // [W+1]
     float marg_int;
-    const int32_t* cond_guide;  // [W][H+1]: entries of the row's CDF that are <= b/H
-    const int32_t* marg_guide;  // [W+1]
     // area: one emissive triangle, radiance (ix, iy, iz) on the side of n = cross(p1-p0, p2-p0)
     float p0[3], p1[3], p2[3], n[3];
     float area;
@@ -99,7 +98,11 @@ struct ShadeScene {
     const DevLight* lights;
     int32_t n_lights;
     int32_t have_frame;
+    int32_t env_staged;         // the environment light whose marginal distribution k_shade keeps in LDS (its W + 1
+                                // records fit RT_MARG_LDS), or -1
 };
+
+#define RT_MARG_LDS 2049        // records of a marginal distribution k_shade can stage in LDS (32 KB)
 
 struct CameraK {
     float pos[3], right[3], up[3], forward[3];
@@ -531,42 +534,47 @@ RT_DEV int find_interval_cdf(const float* cdf, int size, float u) {
     }
     return (int)clampf((float)(first - 1), 0.f, (float)(size - 2));
 }
-// The same interval found through a guide table (guide[b] = number of CDF
-// entries <= b/n): the CDF is non-decreasing, so the partition point of
-// `cdf[i] <= u` is unique and lies between the guide entries one bucket below
-// and two above floor(u*n) (the margin absorbs the rounding of u*n and b/n).
-// Two or three dependent loads instead of log2(n).
-RT_DEV int find_interval_guided(const float* cdf, const int32_t* guide, int n, float u) {
+// Record i of a packed Distribution1D with n entries (i = 0..n):
+//   x = cdf[i], y = cdf[i+1] (i < n), z = func[i] (i < n),
+//   w = bits: guide bracket of bucket i = (lo | hi << 16) with lo = guide[max(i-1, 0)], hi = guide[min(i+2, n)],
+// guide[b] = number of CDF entries <= b/n.  The CDF is non-decreasing, so the partition point of `cdf[k] <= u`
+// that findInterval looks for (src/scene/Common.hpp:13-25) is unique and lies inside the bracket of bucket
+// floor(u*n) (one bucket of margin each side absorbs the rounding of u*n and b/n): the search below probes the same
+// predicate over a shorter range and lands on the same interval.
+// src/samplers/Distributions.cpp:26-35
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) f32x4* GlobalPack;   // pointers read out of a DevLight are generic to the compiler
+typedef const __attribute__((address_space(1))) float* GlobalFloats;
+typedef const __attribute__((address_space(3))) f32x4* LdsPack;   // said outright: a generic pointer would read through flat loads
+template <typename Ptr>
+RT_DEV float dist1d_sample(Ptr pack, float funcInt, int n, float u, float& pdf, int& off) {
     int b = (int)(u * (float)n);
     b = b < 0 ? 0 : (b > n - 1 ? n - 1 : b);
-    const int lo = guide[b > 0 ? b - 1 : 0];
-    const int hi = guide[b + 2 < n ? b + 2 : n];
+    const uint32_t g = __float_as_uint(pack[b].w);
+    const int lo = (int)(g & 0xFFFFu), hi = (int)(g >> 16);
     // entries below lo are <= u and entries from hi on are > u by construction
     int first = lo, len = hi - lo;
     while (len > 0) {
         int half = len >> 1, middle = first + half;
-        if (cdf[middle] <= u) {
+        if (pack[middle].x <= u) {
             first = middle + 1;
             len -= half + 1;
         } else
             len = half;
     }
-    return (int)clampf((float)(first - 1), 0.f, (float)(n - 1));
-}
-// src/samplers/Distributions.cpp:26-35
-RT_DEV float dist1d_sample(const float* cdf, const float* func, const int32_t* guide, float funcInt, int n, float u, float& pdf, int& off) {
-    int offset = find_interval_guided(cdf, guide, n, u);
+    const int offset = (int)clampf((float)(first - 1), 0.f, (float)(n - 1));
     off = offset;
-    float c0 = cdf[offset], c1 = cdf[offset + 1];
-    float du = u - c0;
-    if ((c1 - c0) > 0) du /= (c1 - c0);
-    pdf = func[offset] / funcInt;
+    const f32x4 e = pack[offset];
+    float du = u - e.x;
+    if ((e.y - e.x) > 0) du /= (e.y - e.x);
+    pdf = e.z / funcInt;
     return ((float)offset + du) / (float)n;
 }
 
 // Bilinear RGBA32F fetch (repeat wrap, texel centres at +0.5); the
 // reference's filterLinear lives in its absent Mango dependency.
-RT_DEV f3 filter_linear(const float4* img, int W, int H, f2 uv) {
+RT_DEV f3 filter_linear(const float4* img_, int W, int H, f2 uv) {
+    const GlobalPack img = (GlobalPack)img_;
     float x = uv.x * (float)W - 0.5f, y = uv.y * (float)H - 0.5f;
     float fx0 = floorf(x), fy0 = floorf(y);
     float fx = x - fx0, fy = y - fy0;
@@ -575,8 +583,8 @@ RT_DEV f3 filter_linear(const float4* img, int W, int H, f2 uv) {
     int xb = (x0 + 1) % W; if (xb < 0) xb += W;
     int ya = y0 % H; if (ya < 0) ya += H;
     int yb = (y0 + 1) % H; if (yb < 0) yb += H;
-    float4 p00 = img[(size_t)ya * W + xa], p10 = img[(size_t)ya * W + xb];
-    float4 p01 = img[(size_t)yb * W + xa], p11 = img[(size_t)yb * W + xb];
+    f32x4 p00 = img[(size_t)ya * W + xa], p10 = img[(size_t)ya * W + xb];
+    f32x4 p01 = img[(size_t)yb * W + xa], p11 = img[(size_t)yb * W + xb];
     f3 top = mk3(p00.x, p00.y, p00.z) * (1.0f - fx) + mk3(p10.x, p10.y, p10.z) * fx;
     f3 bot = mk3(p01.x, p01.y, p01.z) * (1.0f - fx) + mk3(p11.x, p11.y, p11.z) * fx;
     return top * (1.0f - fy) + bot * fy;
@@ -623,6 +631,16 @@ RT_DEV f3 tex_trilinear(const ShadeScene& sc, const DevTexture t, f2 uv, float4 
 }
 RT_DEV f2 fract2(f2 v) { f2 r; r.x = v.x - floorf(v.x); r.y = v.y - floorf(v.y); return r; }
 
+// The 36-float attribute block of a triangle (144 bytes, 16-byte aligned) as nine 16-byte loads.
+RT_DEV void load_tri_attr(const float* tri_attr, int32_t tri, float (&a)[36]) {
+    const float4* p = reinterpret_cast<const float4*>(tri_attr) + (size_t)tri * 9;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float4 q = p[k];
+        a[4 * k] = q.x; a[4 * k + 1] = q.y; a[4 * k + 2] = q.z; a[4 * k + 3] = q.w;
+    }
+}
+
 // UV of a hit: the uv part of BVH::postIntersect (src/scene/BVH.cpp:172-187)
 RT_DEV f2 hit_uv(const float* tri_attr, int32_t id1, float hu, float hv) {
     const float* at = tri_attr + (size_t)(id1 / 3) * 36;
@@ -643,7 +661,7 @@ RT_DEV f2 hit_uv(const float* tri_attr, int32_t id1, float hu, float hv) {
 // emissive triangle; the reference only names the type, LightSource.hpp:15)
 // follow the published DiffuseAreaLight-over-Triangle model: uniform area
 // sampling, pdf dist^2 / (|cos| area), one-sided emission.
-RT_DEV f3 light_sample(const DevLight& l, f3 p, f2 u, f3& in, float& pdf, float& tmax) {
+RT_DEV f3 light_sample(const DevLight& l, f3 p, f2 u, f3& in, float& pdf, float& tmax, const float4* lds_marg) {
     tmax = __builtin_inff();
     if (l.type == RT_LIGHT_POINT_K) {
         f3 lp = mk3(l.px, l.py, l.pz);
@@ -672,9 +690,10 @@ RT_DEV f3 light_sample(const DevLight& l, f3 p, f2 u, f3& in, float& pdf, float&
     // Distribution2D::sampleContinuous, src/samplers/Distributions.cpp:60-68
     float pdf0, pdf1;
     int v, dummy;
-    float d1 = dist1d_sample(l.marg_cdf, l.cond_int, l.marg_guide, l.marg_int, l.W, u.y, pdf1, v);
-    float d0 = dist1d_sample(l.cond_cdf + (size_t)v * (l.H + 1), l.cond_func + (size_t)v * l.H, l.cond_guide + (size_t)v * (l.H + 1),
-                             l.cond_int[v], l.H, u.x, pdf0, dummy);
+    // the marginal's records sit in LDS when the workgroup staged them (lds_marg), else in global memory
+    float d1 = lds_marg ? dist1d_sample((LdsPack)lds_marg, l.marg_int, l.W, u.y, pdf1, v)
+                        : dist1d_sample((GlobalPack)(l.marg_pack), l.marg_int, l.W, u.y, pdf1, v);
+    float d0 = dist1d_sample((GlobalPack)(l.cond_pack) + (size_t)v * (l.H + 1), ((GlobalFloats)l.cond_int)[v], l.H, u.x, pdf0, dummy);
     float mapPdf = pdf0 * pdf1;
     pdf = 0.0f;
     in = mk3(0.f, 0.f, 0.f);
@@ -705,7 +724,7 @@ RT_DEV float light_pdf(const DevLight& l, f3 p, f3 inW) {
     float p0 = phi * kInv2Pi, p1 = theta * kInvPi;
     int iu = (int)clampf((float)(int)(p0 * l.H), 0.f, (float)(l.H - 1));
     int iv = (int)clampf((float)(int)(p1 * l.W), 0.f, (float)(l.W - 1));
-    float dp = l.cond_func[(size_t)iv * l.H + iu] / l.marg_int;
+    float dp = ((GlobalPack)l.cond_pack)[(size_t)iv * (l.H + 1) + iu].z / l.marg_int;
     return dp / (2 * kPi * kPi * sinT);
 }
 // src/lights/LightSource.hpp:28-30, src/lights/EnvLight.cpp:60-65
@@ -848,10 +867,18 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
                                                     ShadowQueue sq,
                                                     unsigned long long* __restrict__ shadow_ray_counter) {
     __shared__ uint32_t s_cnt[RT_BLOCK / 64 + 1];
+    __shared__ float4 s_marg[RT_MARG_LDS];
     const uint32_t count = *d_count;
     const uint32_t gsize = gridDim.x * RT_BLOCK;
     const size_t n = pb.n;
     const int L = sc.n_lights;
+    // The marginal distribution of the environment light (every path searches it once per bounce) is staged in LDS
+    // by the workgroups that have paths to shade.
+    if (sc.env_staged >= 0 && blockIdx.x * RT_BLOCK < count) {
+        const DevLight& el = sc.lights[sc.env_staged];
+        for (int k = threadIdx.x; k <= el.W; k += RT_BLOCK) s_marg[k] = el.marg_pack[k];
+        __syncthreads();
+    }
     uint32_t n_emit = 0;   // shadow rays this wave queued (wave-uniform)
     // every thread of a workgroup runs the same number of iterations (barriers inside)
     for (uint32_t bbase = blockIdx.x * RT_BLOCK; bbase < count; bbase += gsize) {
@@ -909,7 +936,8 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
             const float t = ht;
             float bc[3] = {1.0f - hu - hv, hu, hv};
             vpos = org + dir * t;
-            const float* at = sc.tri_attr + (size_t)(id1 / 3) * 36;
+            float at[36];
+            load_tri_attr(sc.tri_attr, id1 / 3, at);
             f3 nrm = mk3(0.f, 0.f, 0.f), tan = mk3(0.f, 0.f, 0.f), bin = mk3(0.f, 0.f, 0.f);
             f2 uv; uv.x = 0.f; uv.y = 0.f;
 #pragma unroll
@@ -981,7 +1009,7 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
                 f2 u;
                 u.x = rng_u01(seed_mixed, pixel, pass, dim_light(depth, L, l, 0));
                 u.y = rng_u01(seed_mixed, pixel, pass, dim_light(depth, L, l, 1));
-                f3 li = light_sample(light, vpos, u, in, lightPdf, tmax);
+                f3 li = light_sample(light, vpos, u, in, lightPdf, tmax, l == sc.env_staged ? s_marg : nullptr);
                 if (lightPdf != 0.0f) {
                     emit = true;
                     f3 bsdfColor = bsdf_f<GLOSSY>(bsdf, out, in);
