@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-set-diagnostics", action="store_true",
                     help="skip the per-set launches made after the timed region (keeps a profile to the timed launches)")
-    ap.add_argument("--render-passes", type=int, default=16, help="sample passes of the path-tracing leg (0 = skip)")
+    ap.add_argument("--render-passes", type=int, default=32, help="sample passes of the path-tracing leg (0 = skip)")
     ap.add_argument("--render-depth", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)

@@ -113,7 +113,7 @@ typedef struct rt_params {
     uint32_t flags;        /* rt_flags; 0 = defaults */
     uint32_t batch;        /* passes rt_render traces together as one wavefront (more rays per launch;
                               path state grows with it: 144 B per pixel slot and 41 B per slot and light, 45 B
-                              with area lights); 0 -> 16, limited by a 48 GiB budget.  The film is
+                              with area lights); 0 -> 32, limited by a 64 GiB budget.  The film is
                               the one that many separate passes leave, bit for bit. */
 } rt_params;
 

@@ -818,17 +818,17 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         }
     }
     c->n_valid = (uint32_t)q0.size();
-    // ---- passes traced together: as many as asked for (default 16) within a
-    // path-state budget of 48 GiB and 32-bit entry indices
+    // ---- passes traced together: as many as asked for (default 32) within a
+    // path-state budget of 64 GiB and 32-bit entry indices
     {
         const uint64_t L1 = (uint64_t)std::max<uint32_t>(1, sd->n_lights);
         // bytes of path state per slot (rays, beta and slot ids twice; hit; L; vertex; status; pixel id; queue entry;
         // deferred list) and of shadow entries per slot and light (direction,
         // contributions, state, deferred list, far bound with area lights)
         const uint64_t per_slot = 144 + (41 + (c->any_area ? 4 : 0)) * L1;
-        uint64_t S = pr->batch ? pr->batch : 16;
+        uint64_t S = pr->batch ? pr->batch : 32;
         const uint64_t one = std::max<uint64_t>(1, (uint64_t)c->n_slots);
-        S = std::min<uint64_t>(S, std::max<uint64_t>(1, (48ull << 30) / (per_slot * one)));
+        S = std::min<uint64_t>(S, std::max<uint64_t>(1, (64ull << 30) / (per_slot * one)));
         S = std::min<uint64_t>(S, std::max<uint64_t>(1, 0x7FFFFFFFull / (L1 * one)));
         S = std::min<uint64_t>(S, 64);
         c->batch = (uint32_t)S;
