@@ -638,6 +638,10 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     c->grid_exact = 8;
     const uint32_t ovf_levels = (uint32_t)std::max(1, c->bvh_max_depth + 2 - RT_STACK_LDS);
     const uint32_t ovf_stride = c->grid_trace * RT_TBLOCK;
+    if ((uint64_t)ovf_levels * ovf_stride * 4ull > 0xFFFFFFFFull) {   // the kernels address it with 32-bit byte offsets
+        c->err = "BVH too deep: the traversal overflow stack would reach 4 GiB";
+        return RT_ERR_LIMIT;
+    }
     if ((r = dev_alloc(c, &c->d_ovf, (size_t)ovf_levels * ovf_stride))) return r;
     // the traversal kernels address nodes (64 B) and triangles (48 B) with 32-bit byte offsets
     if ((uint64_t)n_node_slots * 64ull > 0xFFFFFFFFull || (uint64_t)T * 48ull > 0xFFFFFFFFull) {

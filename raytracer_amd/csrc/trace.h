@@ -109,12 +109,13 @@ RT_DEV bool slab_test_fast(f3 org, f3 inv, float bx0, float by0, float bz0, floa
 // wave-uniform vote instead of a per-lane branch measured 1-4 % slower: some
 // lane of a wave is that deep most of the time.)
 struct LaneStack {
-    int32_t* lds;      // &stack[tid]
-    int32_t* ovf;      // &ovf[gtid]
-    uint32_t ovf_stride;
+    int32_t* lds;                  // &stack[tid]
+    __amdgpu_buffer_rsrc_t ovf;    // the overflow buffer [level - RT_STACK_LDS][grid thread] as a buffer resource
+    uint32_t ovf_lane;             // byte offset of this thread's column
+    uint32_t ovf_pitch;            // bytes per level
     RT_DEV void push(int sp, int32_t x) const {
         if (sp < RT_STACK_LDS) lds[sp * RT_TBLOCK] = x;
-        else ovf[(size_t)(sp - RT_STACK_LDS) * ovf_stride] = x;
+        else __builtin_amdgcn_raw_buffer_store_b32((uint32_t)x, ovf, (int)((uint32_t)(sp - RT_STACK_LDS) * ovf_pitch + ovf_lane), 0, 0);
     }
     RT_DEV int32_t pop(int sp) const {
         int32_t x;
@@ -122,7 +123,7 @@ struct LaneStack {
             x = lds[sp * RT_TBLOCK];
             asm volatile("" : "+v"(x));  // keeps this a ds_read (see the node fetch)
         } else {
-            x = ovf[(size_t)(sp - RT_STACK_LDS) * ovf_stride];
+            x = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(ovf, (int)((uint32_t)(sp - RT_STACK_LDS) * ovf_pitch + ovf_lane), 0, 0);
         }
         return x;
     }
@@ -262,8 +263,10 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
     uint32_t* next = &work->next_exact;   // EXACT launches: one counter over the deferred list
     LaneStack stk;
     stk.lds = lds_stack + tid;
-    stk.ovf = sc.ovf + gtid;
-    stk.ovf_stride = sc.ovf_stride;
+    // 32-bit byte offsets: the host keeps levels x grid threads x 4 bytes below 4 GiB (at most 64 levels x 2^19 threads)
+    stk.ovf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.ovf, (short)0, (int)(sc.ovf_levels * sc.ovf_stride * 4u), 0x00020000);
+    stk.ovf_lane = gtid * 4u;
+    stk.ovf_pitch = sc.ovf_stride * 4u;
     // Items a wave takes from the shared counter at a time: RT_CHUNK when
     // there is plenty of work (few atomics, contiguous rays per wave), fewer
     // when the launch is small, so that a short queue spreads over many waves
