@@ -193,3 +193,19 @@ def test_render_is_deterministic_at_full_size():
     mine = ((ty // 64) * (-(-W // 64)) + tx // 64) % 2 == 0
     assert np.array_equal(_bits(half[mine]), _bits(films[0][mine]))
     assert not half[~mine].any()
+
+
+def test_direct_lighting_closed_form_on_the_gpu():
+    """The integrator against an answer computed by hand, not by the oracle: Lambertian plane, one point light,
+    depth 1 (tests/test_oracle_kats.py: direct_lighting_case): L = color / pi * I / dist^2, no cosine term
+    (src/cpu/PathTracer.cpp:106-107)."""
+    from tests.test_oracle_kats import direct_lighting_case
+    s, want, ok = direct_lighting_case(16, 12)
+    H, W = ok.shape
+    ctx = Context(s, W, H, max_depth=1, seed=0, tile_size=8)
+    ctx.set_camera(s.camera)
+    ctx.render(3)        # the running mean of three identical passes
+    film = ctx.read_film()
+    ctx.close()
+    assert np.allclose(film[ok][:, :3], want[ok], rtol=2e-5, atol=0)
+    assert not film[~ok][:, :3].any()

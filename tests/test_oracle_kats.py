@@ -296,3 +296,41 @@ def test_camera_center_column_hits_nothing(cornell):
     id1 = id1.reshape(64, 64)
     assert (id1[:, 32] == -1).all() and (id1[32, :] == -1).all()
     assert (id1[20:31, 20:31] >= 0).all()
+
+
+# ------------------------------------------------- integrator, closed form
+def direct_lighting_case(W=8, H=6):
+    """A Lambertian plane (Oren-Nayar with sigma = 0) under one point light, depth 1: every pixel whose camera ray
+    hits has the closed form  L = (color / pi) * I / |light - p|^2  -- src/cpu/PathTracer.cpp:106-107 adds
+    beta * f * Li / pdf with NO cosine term, PointLight::sampleLi (src/lights/PointLight.cpp:14-18) gives
+    Li = I / dist^2 and pdf = 1, and Diffuse::f (src/bsdf/Diffuse.cpp:13-32) is color / pi at sigma = 0.
+    Returns (scene, expected (H, W, 3) float64, mask of pixels whose ray has no zero direction component)."""
+    light_pos, inten = np.array([0.3, 0.2, 2.0]), np.array([7.0, 5.0, 3.0])
+    s = soup([((-10, -10, 0), (10, -10, 0), (10, 10, 0)), ((-10, -10, 0), (10, 10, 0), (-10, 10, 0))],
+             lights=[scenes.Light(scenes.LIGHT_POINT, light_pos.astype(np.float32), inten.astype(np.float32))])
+    s.materials[:, 3] = 0.0          # roughness = sigma = 0
+    color = s.materials[0, :3].astype(np.float64)
+    cam = s.camera                   # at (0, 0, 5) looking down -z: right = +x, up = +y
+    want = np.zeros((H, W, 3))
+    ok = np.zeros((H, W), bool)
+    for y in range(H):
+        for x in range(W):
+            ni, nj = x / W - 0.5, -(y / H - 0.5) * (H / W)
+            d = np.array([ni, nj, -1.0])
+            d /= np.linalg.norm(d)
+            ok[y, x] = ni != 0 and nj != 0      # a zero component misses every box (src/scene/Ray.hpp:19-23)
+            p = cam.pos.astype(np.float64) + d * (5.0 / -d[2])
+            want[y, x] = color / math.pi * inten / np.sum((light_pos - p) ** 2)
+    return s, want, ok
+
+
+def test_direct_lighting_has_the_closed_form_without_a_cosine():
+    s, want, ok = direct_lighting_case()
+    H, W = ok.shape
+    film, cnt = ob.OracleScene(s).render(s.camera, W, H, 1, 0, 1)
+    assert np.allclose(film[ok][:, :3], want[ok], rtol=2e-5, atol=0)
+    assert np.all(film[ok][:, 3] == 1.0)
+    assert not film[~ok][:, :3].any()            # axis-parallel camera rays hit nothing; no env light: black
+    # with the cosine the centre-ish pixels would be darker by |n . in| < 1: the closed form above is not that
+    # one shadow ray per hit; the reference also traces the ray of the last bounce whose result it never reads
+    assert cnt["shadow"] == int(ok.sum()) and W * H <= cnt["closest"] <= W * H + int(ok.sum())
