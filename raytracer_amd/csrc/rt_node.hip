@@ -77,6 +77,7 @@ struct rt_node {
     Rccl rccl;
     std::vector<ncclComm_t> comms;
     std::string err;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;   // on devices[0]: bracket the all-gather
     float last_gather_ms = 0.f;
 };
 
@@ -171,6 +172,8 @@ int node_create_impl(rt_node* nd, const rt_scene_desc* scene, const rt_params* p
     }
     NODE_HIP(nd, hipSetDevice(devices[0]));
     NODE_HIP(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_film), (size_t)nd->width * nd->height * 4 * sizeof(float)));
+    NODE_HIP(nd, hipEventCreate(&nd->ev0));
+    NODE_HIP(nd, hipEventCreate(&nd->ev1));
     if (!load_rccl(nd->rccl, nd->err)) return RT_ERR_NO_DEVICE;
     nd->comms.assign(n, nullptr);
     NODE_NCCL(nd, nd->rccl.CommInitAll(nd->comms.data(), n, nd->devices.data()));
@@ -194,7 +197,12 @@ void rt_node_destroy(rt_node* nd) {
         if (i < (int)nd->d_gathered.size() && nd->d_gathered[i]) (void)hipFree(nd->d_gathered[i]);
         if (i < (int)nd->ctx.size() && nd->ctx[i]) rt_destroy(nd->ctx[i]);
     }
-    if (nd->d_film) { (void)hipSetDevice(nd->devices[0]); (void)hipFree(nd->d_film); }
+    if (nd->d_film || nd->ev0 || nd->ev1) {
+        (void)hipSetDevice(nd->devices[0]);
+        if (nd->d_film) (void)hipFree(nd->d_film);
+        if (nd->ev0) (void)hipEventDestroy(nd->ev0);
+        if (nd->ev1) (void)hipEventDestroy(nd->ev1);
+    }
     (void)hipGetLastError();   // a failed create must not leave a stale error behind for the next HIP call to report
     delete nd;
 }
@@ -249,11 +257,8 @@ int rt_node_gather_film(rt_node* nd, const float** d_film_out) {
         return nf ? rt_copy_film_slab(nd->ctx[i], nd->d_local[i], nf) : (int)RT_OK;
     });
     if (r != RT_OK) return r;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
     NODE_HIP(nd, hipSetDevice(nd->devices[0]));
-    NODE_HIP(nd, hipEventCreate(&e0));
-    NODE_HIP(nd, hipEventCreate(&e1));
-    NODE_HIP(nd, hipEventRecord(e0, nd->streams[0]));
+    NODE_HIP(nd, hipEventRecord(nd->ev0, nd->streams[0]));
     NODE_NCCL(nd, nd->rccl.GroupStart());
     for (int i = 0; i < n; ++i) {
         ncclResult_t g = nd->rccl.AllGather(nd->d_local[i], nd->d_gathered[i], nd->per_rank, kNcclFloat, nd->comms[i], nd->streams[i]);
@@ -269,11 +274,9 @@ int rt_node_gather_film(rt_node* nd, const float** d_film_out) {
         NODE_HIP(nd, hipStreamSynchronize(nd->streams[i]));
     }
     NODE_HIP(nd, hipSetDevice(nd->devices[0]));
-    NODE_HIP(nd, hipEventRecord(e1, nd->streams[0]));
-    NODE_HIP(nd, hipEventSynchronize(e1));
-    NODE_HIP(nd, hipEventElapsedTime(&nd->last_gather_ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    NODE_HIP(nd, hipEventRecord(nd->ev1, nd->streams[0]));
+    NODE_HIP(nd, hipEventSynchronize(nd->ev1));
+    NODE_HIP(nd, hipEventElapsedTime(&nd->last_gather_ms, nd->ev0, nd->ev1));
     // the scatter runs on the first context's stream and returns when it is done
     r = rt_unpack_slabs_dev(nd->ctx[0], n, nd->d_gathered[0], nd->per_rank, nd->d_film);
     if (r != RT_OK) { nd->err = rt_last_error(nd->ctx[0]); return r; }
