@@ -65,11 +65,12 @@ def gather_film_device(ctx: Context, group=None) -> torch.Tensor:
 
 def gather_film(ctx: Context, group=None) -> np.ndarray:
     """Gathers the tile-sharded film of a multi-rank render into host memory (what the reference's
-    `Integrator::sync()` hands to the presenter, src/cpu/Integrator.cpp:21-24)."""
+    `Integrator::sync()` hands to the presenter, src/cpu/Integrator.cpp:21-24).  The array is a pinned buffer kept on
+    the context: the next call on the same context overwrites it."""
     film = gather_film_device(ctx, group)
     host = getattr(ctx, "_gather_host", None)
     if host is None or host.shape != film.shape:
         host = torch.empty(film.shape, dtype=torch.float32, pin_memory=True)   # kept: pinning 133 MB takes milliseconds
         ctx._gather_host = host
     host.copy_(film)
-    return host.numpy().copy()
+    return host.numpy()
