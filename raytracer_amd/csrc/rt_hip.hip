@@ -122,6 +122,8 @@ struct rt_ctx {
     uint32_t* d_counts_init = nullptr;  // template copied in at the start of a pass
     uint32_t n_counts = 0;
     ShadowQueue sq{};                      // shadow entries of the bounce being resolved
+    int32_t* d_light_list = nullptr;       // [L] all lights, then [n_uncached] the lights without cached primary visibility
+    int n_uncached_lights = 0;
     uint32_t* d_pass_deferred_b = nullptr; // deferred list of the shadow launches
     unsigned long long* d_raystats = nullptr;  // [0] closest, [1] shadow, [2] / [3] of those, rays re-traced by the exact follow-up launches
     TraceWork* d_work = nullptr;               // work counters of the rt_trace_* launches
@@ -428,21 +430,26 @@ int run_pass(rt_ctx* c, uint32_t nb) {
             hipLaunchKernelGGL(k_shade<false>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, prime, seed_mixed, pass, qin, cnt_in,
                                cnt_out, c->sq, c->d_raystats + 1);
         TraceWork* w = work + d;
+        // the shadow entries this bounce's traversal launch walks (at bounce 0 the cached ones are already resolved)
+        ShadowQueue sqd = c->sq;
+        const bool cached0 = d == 0 && !prime;
+        sqd.trace_lights = c->d_light_list + (cached0 ? L : 0);
+        sqd.n_trace = cached0 ? c->n_uncached_lights : L;
         if (d + 1 < D) {
-            hipLaunchKernelGGL(k_bounce<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, cnt_out, w,
+            hipLaunchKernelGGL(k_bounce<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, cnt_out, w,
                                c->d_pass_deferred_b, c->d_raystats);
-            hipLaunchKernelGGL(k_bounce<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, cnt_out,
+            hipLaunchKernelGGL(k_bounce<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, cnt_out,
                                w, c->d_pass_deferred_b, c->d_raystats);
         } else if (L > 0) {
             if (c->any_area) {   // shadow rays towards area lights stop at the light
-                hipLaunchKernelGGL((k_shadow<false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, w,
+                hipLaunchKernelGGL((k_shadow<false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, w,
                                    c->d_pass_deferred_b, c->d_raystats + 1);
-                hipLaunchKernelGGL((k_shadow<true, true>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in,
+                hipLaunchKernelGGL((k_shadow<true, true>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in,
                                    w, c->d_pass_deferred_b, c->d_raystats + 1);
             } else {
-                hipLaunchKernelGGL((k_shadow<false, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in, w,
+                hipLaunchKernelGGL((k_shadow<false, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, w,
                                    c->d_pass_deferred_b, c->d_raystats + 1);
-                hipLaunchKernelGGL((k_shadow<true, false>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, c->sq, L, qin, cnt_in,
+                hipLaunchKernelGGL((k_shadow<true, false>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in,
                                    w, c->d_pass_deferred_b, c->d_raystats + 1);
             }
         }
@@ -785,6 +792,13 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
             }
         }
         if ((r = dev_upload(c, &c->d_lights, lights.data(), lights.size()))) return r;
+        // work lists of the traversal launches: every light; the lights whose shadow ray from the primary vertex is
+        // not kept in the per-camera cache (everything but point lights)
+        std::vector<int32_t> list;
+        for (uint32_t l = 0; l < sd->n_lights; ++l) list.push_back((int32_t)l);
+        for (uint32_t l = 0; l < sd->n_lights; ++l)
+            if (sd->lights[l].type != RT_LIGHT_POINT) { list.push_back((int32_t)l); ++c->n_uncached_lights; }
+        if ((r = dev_upload(c, &c->d_light_list, list.data(), list.size()))) return r;
     }
     c->ss.tri_attr = c->d_tri_attr;
     c->ss.materials = c->d_materials;

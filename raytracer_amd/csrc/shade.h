@@ -847,6 +847,10 @@ struct ShadowQueue {
     float* contrib;    // 6 planes of cap
     uint8_t* state;    // [cap]
     uint32_t cap;      // n_lights * n_slots
+    // The lights whose entries the traversal launch of this bounce walks: all of them, or, at bounce 0 of a pass
+    // that reads the per-camera cache, only those whose shadow ray is not cached (k_shade has resolved the others).
+    const int32_t* trace_lights;
+    int32_t n_trace;
 };
 
 // One bounce of src/cpu/PathTracer.cpp:56-65 (d = 0 miss) and :95-144 for
@@ -1105,15 +1109,15 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_shadow(TraceScene ts,
     const TopTree top = stage_top_tree(ts.nodes, ts.n_nodes, s_top);
     const uint32_t paths = *d_count;
     // work item j = (light j / paths, path-queue entry j % paths)
-    const uint32_t count = EXACT ? work->n_deferred : paths * (uint32_t)n_lights;
+    const uint32_t count = EXACT ? work->n_deferred : paths * (uint32_t)q.n_trace;
     const size_t n = pb.n, cap = q.cap;
     if (EXACT && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(ray_counter + 2, (unsigned long long)count);
     // work item j -> (light, path index); `queue` lists the path indices at bounce 0 and is null afterwards
     auto entry = [&](uint32_t j, uint32_t& s) -> size_t {
-        const uint32_t l = j / paths;
-        const uint32_t e = j - l * paths;
+        const uint32_t li = j / paths;
+        const uint32_t e = j - li * paths;
         s = queue ? queue[e] : e;
-        return (size_t)l * n + s;
+        return (size_t)q.trace_lights[li] * n + s;
     };
     auto mark = [&](uint32_t j, const HitRec& h) {
         uint32_t s;
@@ -1163,7 +1167,7 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_bounce(TraceScene ts,
     __shared__ __attribute__((aligned(16))) char s_top[RT_TOP_BYTES];
     const TopTree top = stage_top_tree(ts.nodes, ts.n_nodes, s_top);
     const uint32_t paths = *d_count, n_next = *d_next_count;
-    const uint32_t count = EXACT ? work->n_deferred : n_next + paths * (uint32_t)n_lights;
+    const uint32_t count = EXACT ? work->n_deferred : n_next + paths * (uint32_t)q.n_trace;
     const size_t n = pb.n, cap = q.cap;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (!EXACT) atomicAdd(ray_counter, (unsigned long long)n_next);   // closest-hit rays; k_shade counted the shadow rays
@@ -1171,10 +1175,10 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_bounce(TraceScene ts,
     }
     auto entry = [&](uint32_t j, uint32_t& s) -> size_t {
         const uint32_t k = j - n_next;
-        const uint32_t l = k / paths;
-        const uint32_t e = k - l * paths;
+        const uint32_t li = k / paths;
+        const uint32_t e = k - li * paths;
         s = queue ? queue[e] : e;
-        return (size_t)l * n + s;
+        return (size_t)q.trace_lights[li] * n + s;
     };
     trace_persistent<false, EXACT, false, true>(
         ts, count, work, deferred, s_stack, top,
