@@ -1095,6 +1095,16 @@ __global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene s
     }
 }
 
+// `probe` of the launches that walk shadow entries: wraps a callable that says whether work item j carries a ray.
+template <typename F>
+struct EntryProbe {
+    static constexpr bool kFilters = true;
+    F f;
+    RT_DEV bool operator()(uint32_t j) const { return f(j); }
+};
+template <typename F>
+RT_DEV EntryProbe<F> make_probe(F f) { return EntryProbe<F>{f}; }
+
 // Traces the bounce's shadow rays, every light in one launch:
 // BVH::occluded from the shaded vertex (src/cpu/PathTracer.cpp:101-102).  An
 // unoccluded ray only marks its (light, slot) state; k_accumulate then adds
@@ -1135,7 +1145,7 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_shadow(TraceScene ts,
                 tfar = q.tmax[e];
                 return true;
             },
-            mark);
+            mark, make_probe([&](uint32_t j) -> bool { uint32_t s; return q.state[entry(j, s)] == 1; }));
     } else {
         trace_persistent<true, EXACT, false>(
             ts, count, work, deferred, s_stack, top,
@@ -1147,7 +1157,7 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_shadow(TraceScene ts,
                 dir = mk3(q.dir[e], q.dir[cap + e], q.dir[2 * cap + e]);
                 return true;
             },
-            mark);
+            mark, make_probe([&](uint32_t j) -> bool { uint32_t s; return q.state[entry(j, s)] == 1; }));
     }
 }
 
@@ -1205,7 +1215,12 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_bounce(TraceScene ts,
                 uint32_t s;
                 if (h.id1 < 0) q.state[entry(j, s)] = 2;
             }
-        });
+        },
+        make_probe([&](uint32_t j) -> bool {
+            if (j < n_next) return true;
+            uint32_t s;
+            return q.state[entry(j, s)] == 1;
+        }));
 }
 
 // After the traversal launch of bounce 0 in the first pass after a camera change: keeps, per film slot and point

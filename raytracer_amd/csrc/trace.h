@@ -253,9 +253,17 @@ __device__ unsigned long long g_probe[16];
 #else
 #define RT_PROBE_ADD(k, v) do { } while (0)
 #endif
-template <bool ANY_HIT, bool EXACT, bool BOUNDED = false, bool MIXED = false, typename Load, typename Done>
+// Default `probe` of trace_persistent: every item carries a ray.
+struct NoProbe {
+    static constexpr bool kFilters = false;
+    RT_DEV bool operator()(uint32_t) const { return true; }
+};
+#ifndef RT_PROBE_ROUNDS
+#define RT_PROBE_ROUNDS 3
+#endif
+template <bool ANY_HIT, bool EXACT, bool BOUNDED = false, bool MIXED = false, typename Load, typename Done, typename Probe = NoProbe>
 RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* work, uint32_t* deferred, int32_t* lds_stack,
-                             const TopTree& top, Load load, Done done) {
+                             const TopTree& top, Load load, Done done, Probe probe = Probe()) {
     const uint32_t tid = threadIdx.x;
     const uint32_t gtid = blockIdx.x * RT_TBLOCK + tid;
     const uint32_t lane = tid & 63u;
@@ -332,14 +340,30 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                 if (!got) exhausted = 1;
             }
             if (c_next < c_end) {
-                const uint32_t avail = c_end - c_next;
-                const uint32_t k = avail < (uint32_t)n_idle ? avail : (uint32_t)n_idle;
-                const uint32_t r = __popcll(m_idle & ((1ull << lane) - 1ull));
-                if (cur <= RT_DONE && r < k) {
+                // Idle lanes take the next items of the chunk.  An item may carry no ray (a shadow entry that was
+                // never queued): `probe` tells from one byte, and a lane that drew such an item draws again, up to
+                // RT_PROBE_ROUNDS times, before the rays of the lanes that found one are loaded together.
+                bool have = false;
+                uint32_t mine = 0;
+#pragma unroll 1
+                for (int round = 0; round < (Probe::kFilters ? RT_PROBE_ROUNDS : 1); ++round) {
+                    const unsigned long long m_want = __ballot(cur <= RT_DONE && !have);
+                    const uint32_t n_want = (uint32_t)__popcll(m_want);
+                    if (n_want == 0 || c_next >= c_end) break;
+                    const uint32_t avail = c_end - c_next;
+                    const uint32_t k = avail < n_want ? avail : n_want;
+                    const uint32_t r = __popcll(m_want & ((1ull << lane) - 1ull));
+                    if (cur <= RT_DONE && !have && r < k) {
+                        uint32_t i = c_next + r;
+                        if (EXACT) i = deferred[i];
+                        if (probe(i)) { have = true; mine = i; }
+                    }
+                    c_next += k;
+                }
+                if (have) {
                     if (cur == RT_DONE) done(item, h);
                     cur = RT_IDLE;
-                    uint32_t i = c_next + r;
-                    if (EXACT) i = deferred[i];
+                    const uint32_t i = mine;
                     item = i;
                     bool present;
                     if constexpr (MIXED) present = load(i, org, dir, tfar, any_lane);
@@ -363,7 +387,6 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                         cur = RT_DONE;   // missed the root box: the (empty) result is still to be written
                     }
                 }
-                c_next += k;
             }
             continue;
         }
