@@ -104,12 +104,18 @@ RT_DEV bool slab_test_fast(f3 org, f3 inv, float bx0, float by0, float bz0, floa
     return (tmin <= tmax) && (tmax > 0.0f);
 }
 
+typedef float tr_f32x4 __attribute__((ext_vector_type(4)));
+typedef int32_t tr_i32x2 __attribute__((ext_vector_type(2)));
+#define RT_LDS __attribute__((address_space(3)))
+// Pointers into LDS are typed as such: through generic pointers the compiler merges the LDS and the global form of
+// a fetch into flat loads of a selected address.
+
 // Per-lane traversal stack: levels below RT_STACK_LDS in LDS, the rest in
 // the global overflow buffer.  (Putting the overflow accesses behind a
 // wave-uniform vote instead of a per-lane branch measured 1-4 % slower: some
 // lane of a wave is that deep most of the time.)
 struct LaneStack {
-    int32_t* lds;                  // &stack[tid]
+    RT_LDS int32_t* lds;           // &stack[tid]
     __amdgpu_buffer_rsrc_t ovf;    // the overflow buffer [level - RT_STACK_LDS][grid thread] as a buffer resource
     uint32_t ovf_lane;             // byte offset of this thread's column
     uint32_t ovf_pitch;            // bytes per level
@@ -121,7 +127,6 @@ struct LaneStack {
         int32_t x;
         if (sp < RT_STACK_LDS) {
             x = lds[sp * RT_TBLOCK];
-            asm volatile("" : "+v"(x));  // keeps this a ds_read (see the node fetch)
         } else {
             x = (int32_t)__builtin_amdgcn_raw_buffer_load_b32(ovf, (int)((uint32_t)(sp - RT_STACK_LDS) * ovf_pitch + ovf_lane), 0, 0);
         }
@@ -166,10 +171,10 @@ RT_DEV bool moderate(float x) { return fabsf(x) < 1e30f; }  // false for NaN and
 // The LDS-resident top of the tree, SoA: node k = (b0[k], b1[k], b2[k]) child
 // boxes (48 B, DevNode's first three float4) and lk[k] = (left, right).
 struct TopTree {
-    const float4* b0;
-    const float4* b1;
-    const float4* b2;
-    const int2* lk;
+    const RT_LDS tr_f32x4* b0;
+    const RT_LDS tr_f32x4* b1;
+    const RT_LDS tr_f32x4* b2;
+    const RT_LDS tr_i32x2* lk;
     int32_t n;   // nodes resident (a prefix of the node array)
 };
 
@@ -191,7 +196,8 @@ RT_DEV TopTree stage_top_tree(const float4* nodes, int32_t n_nodes, char* lds) {
     }
     __syncthreads();
     TopTree t;
-    t.b0 = b0; t.b1 = b1; t.b2 = b2; t.lk = lk; t.n = n;
+    t.b0 = (const RT_LDS tr_f32x4*)b0; t.b1 = (const RT_LDS tr_f32x4*)b1; t.b2 = (const RT_LDS tr_f32x4*)b2;
+    t.lk = (const RT_LDS tr_i32x2*)lk; t.n = n;
     return t;
 }
 
@@ -270,7 +276,7 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
     const float inf = __builtin_inff();
     uint32_t* next = &work->next_exact;   // EXACT launches: one counter over the deferred list
     LaneStack stk;
-    stk.lds = lds_stack + tid;
+    stk.lds = (RT_LDS int32_t*)lds_stack + tid;
     // 32-bit byte offsets: the host keeps levels x grid threads x 4 bytes below 4 GiB (at most 64 levels x 2^19 threads)
     stk.ovf = __builtin_amdgcn_make_buffer_rsrc((void*)sc.ovf, (short)0, (int)(sc.ovf_levels * sc.ovf_stride * 4u), 0x00020000);
     stk.ovf_lane = gtid * 4u;
@@ -402,13 +408,10 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     float4 a, b, c;
                     int32_t left, right;
                     if (cur < top.n) {
-                        a = top.b0[cur]; b = top.b1[cur]; c = top.b2[cur];
-                        int2 l2 = top.lk[cur];
+                        const tr_f32x4 la = top.b0[cur], lb = top.b1[cur], lc = top.b2[cur];
+                        const tr_i32x2 l2 = top.lk[cur];
+                        a = make_float4(la.x, la.y, la.z, la.w); b = make_float4(lb.x, lb.y, lb.z, lb.w); c = make_float4(lc.x, lc.y, lc.z, lc.w);
                         left = l2.x; right = l2.y;
-                        // pins these as LDS reads: without it the compiler folds the two
-                        // branches into flat-address loads of a selected pointer
-                        asm volatile("" : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(a.w), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.w), "+v"(c.x), "+v"(c.y),
-                                     "+v"(c.z), "+v"(c.w), "+v"(left), "+v"(right));
                     } else {
                         // through a buffer resource: one 32-bit offset instead of a 64-bit address per lane
                         const uint32_t off = (uint32_t)cur << 6;   // < 4 GiB: checked by the host
