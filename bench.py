@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--render-depth", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--bvh", choices=("binary", "wide"), default="wide",
+                    help="tree the closest-hit launch walks: the reference's binary LBVH (bit-exact ids) or its 4-wide collapse "
+                         "(same distances; ids may differ where several triangles lie at exactly the same distance)")
     args = ap.parse_args()
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be at least 1")
@@ -121,7 +124,7 @@ def main():
 
     W, H = args.width, args.height
     scene = scenes.sponza_class()
-    ctx = Context(scene, W, H, max_depth=args.render_depth, seed=0, device=local_rank)
+    ctx = Context(scene, W, H, max_depth=args.render_depth, seed=0, device=local_rank, wide_bvh=(args.bvh == "wide"))
     n = W * H
     coherent = scenes.camera_rays_numpy(scene.camera, W, H)
     incoherent = scenes.incoherent_rays(scene, n, seed=0x5EED + rank)

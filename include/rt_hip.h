@@ -118,7 +118,13 @@ typedef struct rt_params {
 } rt_params;
 
 enum rt_flags {
-    RT_FLAG_HOST_BVH = 1   /* build the LBVH with the host builder instead of on the GPU (same tree) */
+    RT_FLAG_HOST_BVH = 1,  /* build the LBVH with the host builder instead of on the GPU (same tree) */
+    RT_FLAG_WIDE_BVH = 2   /* also collapse the LBVH into 4-wide nodes on the GPU and let rt_trace_closest* /
+                              rt_trace_occluded* walk those: the same triangles are reachable and the same
+                              distance is returned, but children are visited in order of their own box distance,
+                              so of several triangles at exactly the same distance another one than the
+                              reference's (src/scene/BVH.cpp:139,160-166) may be reported.  Any-hit results are
+                              identical. */
 };
 
 typedef struct rt_stats {
@@ -245,6 +251,11 @@ int rt_trace_closest_noalloc(rt_ctx* ctx, uint32_t n, const float* d_rays_soa, f
  * query n_nodes only. */
 int rt_get_bvh(rt_ctx* ctx, uint32_t* n_nodes, float* boxes, int32_t* left, int32_t* right,
                int32_t* tri, int32_t* model, int32_t* leaf);
+
+/* Diagnostic: the 4-wide nodes (RT_FLAG_WIDE_BVH), 32 floats each: six planes of four (min x, min y, min z,
+ * max x, max y, max z of the four children), four int32 links (>= 0 wide node, < 0 ~slot of a leaf in Morton
+ * order), then the slot count, the binary node id and two zeros.  Pass nodes32 = null to query the counts. */
+int rt_get_wide_bvh(rt_ctx* ctx, uint32_t* n_nodes, int32_t* depth, float* nodes32);
 
 /* Host-only run of the same LBVH builder (no device needed): fills the
  * reference-layout node arrays for n_indices/3 triangles; every array holds

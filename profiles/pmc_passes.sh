@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python3 $R/bench.py --steps 5 --warmup 2 --render-passes 0 --no-cpu-baseline --no-set-diagnostics"
+CMD="python3 $R/bench.py --steps 5 --warmup 2 --render-passes 0 --no-cpu-baseline --no-set-diagnostics $BENCH_ARGS"
 timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $CMD > $OUT/stats.log 2>&1
 pass() { name=$1; shift; if [ -n "$PASSES" ] && [[ " $PASSES " != *" $name "* ]]; then return 0; fi; timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $OUT/$name -- $CMD > $OUT/$name.log 2>&1; }
 pass fetch FETCH_SIZE

@@ -60,6 +60,7 @@ class rt_params(C.Structure):
 
 
 RT_FLAG_HOST_BVH = 1
+RT_FLAG_WIDE_BVH = 2
 RT_NOALLOC_MAX_RAYS = 1 << 22   # rays per rt_trace_closest_noalloc call
 
 
@@ -79,6 +80,7 @@ EXPORTS = [
     "rt_read_primary_duv", "rt_trace_occluded_bounded", "rt_read_last_bounce_rays", "rt_trace_closest_noalloc",
     "rt_node_create", "rt_node_destroy", "rt_node_last_error", "rt_node_device_count", "rt_node_context", "rt_node_set_camera",
     "rt_node_reset_accumulation", "rt_node_render", "rt_node_gather_film", "rt_node_read_film", "rt_node_last_gather_ms",
+    "rt_get_wide_bvh",
 ]
 
 
@@ -123,6 +125,7 @@ def load_library():
     lib.rt_trace_occluded_dev.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32]
     lib.rt_trace_closest_noalloc.argtypes = [vp, C.c_uint32, vp, vp, vp, vp, vp, vp]
     lib.rt_get_bvh.argtypes = [vp, up, fp, ip, ip, ip, ip, ip]
+    lib.rt_get_wide_bvh.argtypes = [vp, up, ip, fp]
     lib.rt_get_stats.argtypes = [vp, C.POINTER(rt_stats)]
     lib.rt_synchronize.argtypes = [vp]
     lib.rt_version.restype = C.c_char_p
@@ -215,12 +218,13 @@ class Context:
     """One rt_ctx: a scene resident on one MI355X plus this rank's share of the film."""
 
     def __init__(self, scene: Scene, width: int, height: int, max_depth: int = 4, seed: int = 0, device: int = 0,
-                 rank: int = 0, world: int = 1, tile_size: int = 64, use_frame: bool = True, host_bvh: bool = False, batch: int = 0):
+                 rank: int = 0, world: int = 1, tile_size: int = 64, use_frame: bool = True, host_bvh: bool = False, batch: int = 0,
+                 wide_bvh: bool = False):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.width, self.height, self.world, self.rank, self.tile_size = width, height, world, rank, tile_size
         d, self._keep = _scene_desc(scene, use_frame)
-        p = rt_params(width, height, max_depth, tile_size, seed, device, rank, world, RT_FLAG_HOST_BVH if host_bvh else 0, batch)
+        p = rt_params(width, height, max_depth, tile_size, seed, device, rank, world, (RT_FLAG_HOST_BVH if host_bvh else 0) | (RT_FLAG_WIDE_BVH if wide_bvh else 0), batch)
         rc = self._lib.rt_create(C.byref(d), C.byref(p), C.byref(self._h))
         if rc != 0:
             raise RtError(rc, self._lib.rt_last_error(None).decode())
@@ -328,6 +332,15 @@ class Context:
         nn = C.c_uint32()
         self._check(self._lib.rt_get_bvh(self._h, C.byref(nn), _fptr(boxes), *[_iptr(a) for a in arrs]))
         return (boxes, *arrs)
+
+    def get_wide_bvh(self):
+        """(nodes, depth): nodes is (n, 32) float32, the 4-wide nodes as rt_get_wide_bvh documents them."""
+        n, d = C.c_uint32(), C.c_int32()
+        self._check(self._lib.rt_get_wide_bvh(self._h, C.byref(n), C.byref(d), None))
+        nodes = np.empty((n.value, 32), np.float32)
+        if n.value:
+            self._check(self._lib.rt_get_wide_bvh(self._h, C.byref(n), C.byref(d), _fptr(nodes)))
+        return nodes, d.value
 
     def stats(self) -> dict:
         st = rt_stats()

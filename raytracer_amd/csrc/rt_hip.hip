@@ -16,6 +16,8 @@
 #include "lbvh_device.h"
 #include "lbvh_host.h"
 #include "shade.h"
+#include "trace_wide.h"
+#include "wide_bvh.h"
 
 using namespace rt;
 
@@ -86,6 +88,8 @@ struct rt_ctx {
     float4* d_nodes = nullptr;
     float4* d_tris = nullptr;
     int32_t* d_ovf = nullptr;
+    WideBvh wide;              // 4-wide collapse of the same tree (RT_FLAG_WIDE_BVH)
+    bool use_wide = false;
     TraceScene ts{};
     uint32_t grid_trace = 0;
 
@@ -327,8 +331,12 @@ int launch_closest(rt_ctx* c, uint32_t n, const float* d_rays, float* d_t, int32
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     for (uint32_t r = 0; r < repeat; ++r) {
         HIP_TRY(c, hipMemsetAsync(c->d_work, 0, sizeof(TraceWork), c->stream));
-        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
-                           c->d_deferred, d_t, d_id0, d_id1, d_u, d_v, c->d_raystats);
+        if (c->use_wide)
+            hipLaunchKernelGGL(k_trace_closest_wide, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
+                               c->d_deferred, d_t, d_id0, d_id1, d_u, d_v, c->d_raystats);
+        else
+            hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
+                               c->d_deferred, d_t, d_id0, d_id1, d_u, d_v, c->d_raystats);
         hipLaunchKernelGGL(k_trace_closest<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
                            c->d_deferred, d_t, d_id0, d_id1, d_u, d_v, c->d_raystats);
     }
@@ -348,14 +356,22 @@ int launch_occluded(rt_ctx* c, uint32_t n, const float* d_rays, int32_t* d_statu
     for (uint32_t r = 0; r < repeat; ++r) {
         HIP_TRY(c, hipMemsetAsync(c->d_work, 0, sizeof(TraceWork), c->stream));
         if (d_tmax) {
-            hipLaunchKernelGGL(k_trace_occluded_bounded<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, d_tmax,
-                               n, n, c->d_work, c->d_deferred, d_status);
+            if (c->use_wide)
+                hipLaunchKernelGGL(k_trace_occluded_wide<true>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, d_tmax,
+                                   n, n, c->d_work, c->d_deferred, d_status);
+            else
+                hipLaunchKernelGGL(k_trace_occluded_bounded<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, d_tmax,
+                                   n, n, c->d_work, c->d_deferred, d_status);
             hipLaunchKernelGGL(k_trace_occluded_bounded<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, d_tmax, n,
                                n, c->d_work, c->d_deferred, d_status);
             continue;
         }
-        hipLaunchKernelGGL(k_trace_occluded<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
-                           c->d_deferred, d_status);
+        if (c->use_wide)
+            hipLaunchKernelGGL(k_trace_occluded_wide<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, nullptr, n, n,
+                               c->d_work, c->d_deferred, d_status);
+        else
+            hipLaunchKernelGGL(k_trace_occluded<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
+                               c->d_deferred, d_status);
         hipLaunchKernelGGL(k_trace_occluded<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, c->d_work,
                            c->d_deferred, d_status);
     }
@@ -398,9 +414,14 @@ int run_pass(rt_ctx* c, uint32_t nb) {
     if (prime) {
         hipLaunchKernelGGL(k_generate, dim3(g1), dim3(RT_BLOCK), 0, c->stream, c->pb, c->cam, c->n_slots);
         // the first n_valid entries of d_q0 are the film slots of the batch's first pass
-        hipLaunchKernelGGL(k_extend<false>, dim3(grid_for(c, c->n_valid)), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.prim_rays, c->n_slots,
-                           c->d_q0, c->d_prime_count, work + D, c->d_pass_deferred, c->pb.prim_t, c->pb.prim_id0, c->pb.prim_id1, c->pb.prim_u,
-                           c->pb.prim_v, c->d_raystats);
+        if (c->use_wide)
+            hipLaunchKernelGGL(k_extend_wide, dim3(grid_for(c, c->n_valid)), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.prim_rays, c->n_slots,
+                               c->d_q0, c->d_prime_count, work + D, c->d_pass_deferred, c->pb.prim_t, c->pb.prim_id0, c->pb.prim_id1,
+                               c->pb.prim_u, c->pb.prim_v, c->d_raystats);
+        else
+            hipLaunchKernelGGL(k_extend<false>, dim3(grid_for(c, c->n_valid)), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.prim_rays, c->n_slots,
+                               c->d_q0, c->d_prime_count, work + D, c->d_pass_deferred, c->pb.prim_t, c->pb.prim_id0, c->pb.prim_id1,
+                               c->pb.prim_u, c->pb.prim_v, c->d_raystats);
         hipLaunchKernelGGL(k_extend<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, c->pb.prim_rays, c->n_slots, c->d_q0,
                            c->d_prime_count, work + D, c->d_pass_deferred, c->pb.prim_t, c->pb.prim_id0, c->pb.prim_id1, c->pb.prim_u,
                            c->pb.prim_v, c->d_raystats);
@@ -436,19 +457,31 @@ int run_pass(rt_ctx* c, uint32_t nb) {
         sqd.trace_lights = c->d_light_list + (cached0 ? L : 0);
         sqd.n_trace = cached0 ? c->n_uncached_lights : L;
         if (d + 1 < D) {
-            hipLaunchKernelGGL(k_bounce<false>, dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, cnt_out, w,
-                               c->d_pass_deferred_b, c->d_raystats);
-            hipLaunchKernelGGL(k_bounce<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, cnt_out,
+            if (c->use_wide)
+                hipLaunchKernelGGL((k_bounce<false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, cnt_out, w,
+                                   c->d_pass_deferred_b, c->d_raystats);
+            else
+                hipLaunchKernelGGL((k_bounce<false, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, cnt_out, w,
+                                   c->d_pass_deferred_b, c->d_raystats);
+            hipLaunchKernelGGL((k_bounce<true, false>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, cnt_out,
                                w, c->d_pass_deferred_b, c->d_raystats);
         } else if (L > 0) {
             if (c->any_area) {   // shadow rays towards area lights stop at the light
-                hipLaunchKernelGGL((k_shadow<false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, w,
-                                   c->d_pass_deferred_b, c->d_raystats + 1);
+                if (c->use_wide)
+                    hipLaunchKernelGGL((k_shadow<false, true, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, w,
+                                       c->d_pass_deferred_b, c->d_raystats + 1);
+                else
+                    hipLaunchKernelGGL((k_shadow<false, true, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, w,
+                                       c->d_pass_deferred_b, c->d_raystats + 1);
                 hipLaunchKernelGGL((k_shadow<true, true>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in,
                                    w, c->d_pass_deferred_b, c->d_raystats + 1);
             } else {
-                hipLaunchKernelGGL((k_shadow<false, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, w,
-                                   c->d_pass_deferred_b, c->d_raystats + 1);
+                if (c->use_wide)
+                    hipLaunchKernelGGL((k_shadow<false, false, true>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, w,
+                                       c->d_pass_deferred_b, c->d_raystats + 1);
+                else
+                    hipLaunchKernelGGL((k_shadow<false, false, false>), dim3(gtrace), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in, w,
+                                       c->d_pass_deferred_b, c->d_raystats + 1);
                 hipLaunchKernelGGL((k_shadow<true, false>), dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, pbd, sqd, L, qin, cnt_in,
                                    w, c->d_pass_deferred_b, c->d_raystats + 1);
             }
@@ -485,6 +518,7 @@ void rt_destroy(rt_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void* p : c->allocs) (void)hipFree(p);
     c->dbvh.release();
+    c->wide.release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -635,6 +669,26 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         c->bvh_max_depth = c->dbvh.max_depth;
         for (int k = 0; k < 3; ++k) { rmin[k] = c->dbvh.root_min[k]; rmax[k] = c->dbvh.root_max[k]; }
     }
+    // ---- the 4-wide collapse of that tree, made on the device from the binary device nodes
+    c->ts.wnodes = nullptr;
+    c->ts.n_wnodes = 0;
+    c->ts.wroot = root_link;
+    if (pr->flags & RT_FLAG_WIDE_BVH) {
+        std::string werr;
+        if (build_wide_bvh(c->d_nodes, root_link, T - 1, c->stream, &c->wide, &werr) != 0) {
+            c->err = "wide BVH collapse: " + werr;
+            return RT_ERR_HIP;
+        }
+        if ((uint64_t)c->wide.n_nodes * 128ull > 0xFFFFFFFFull) {
+            c->err = "scene too large: the wide node array reaches 4 GiB";
+            return RT_ERR_LIMIT;
+        }
+        c->use_wide = true;
+        c->ts.wnodes = c->wide.nodes;
+        c->ts.n_wnodes = (int32_t)c->wide.n_nodes;
+        c->ts.wroot = c->wide.n_nodes ? 0 : root_link;
+        c->device_bytes += (uint64_t)c->wide.capacity * 128ull;
+    }
     c->bvh_build_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
     // persistent traversal grid: as many workgroups per CU as LDS and registers admit
@@ -643,7 +697,8 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
     if (bpc < 1) bpc = 1;
     c->grid_trace = (uint32_t)c->num_cu * (uint32_t)bpc;
     c->grid_exact = 8;
-    const uint32_t ovf_levels = (uint32_t)std::max(1, c->bvh_max_depth + 2 - RT_STACK_LDS);
+    // pending entries of a lane: at most one per binary level, at most three per wide level
+    const uint32_t ovf_levels = (uint32_t)std::max(1, std::max(c->bvh_max_depth + 2 - RT_STACK_LDS, 3 * c->wide.depth + 2 + RT_WSPILL));
     const uint32_t ovf_stride = c->grid_trace * RT_TBLOCK;
     if ((uint64_t)ovf_levels * ovf_stride * 4ull > 0xFFFFFFFFull) {   // the kernels address it with 32-bit byte offsets
         c->err = "BVH too deep: the traversal overflow stack would reach 4 GiB";
@@ -1282,6 +1337,16 @@ int rt_lbvh_host(const float* pos, uint32_t pos_stride, const uint32_t* indices,
         left[i] = res.ref[i].left; right[i] = res.ref[i].right; tri[i] = res.ref[i].tri; model[i] = res.ref[i].model;
         leaf[i] = res.ref[i].leaf;
     }
+    return RT_OK;
+}
+
+int rt_get_wide_bvh(rt_ctx* c, uint32_t* n_nodes, int32_t* depth, float* nodes32) {
+    if (!c || !n_nodes) return RT_ERR_ARG;
+    *n_nodes = c->wide.n_nodes;
+    if (depth) *depth = c->wide.depth;
+    if (!nodes32 || !c->wide.n_nodes) return RT_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(nodes32, c->wide.nodes, (size_t)c->wide.n_nodes * 128, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 

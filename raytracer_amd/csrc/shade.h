@@ -7,6 +7,7 @@
 // (compacted by k_shade with one atomic per workgroup).
 #pragma once
 #include "trace.h"
+#include "trace_wide.h"
 
 namespace rt {
 
@@ -1109,14 +1110,16 @@ RT_DEV EntryProbe<F> make_probe(F f) { return EntryProbe<F>{f}; }
 // BVH::occluded from the shaded vertex (src/cpu/PathTracer.cpp:101-102).  An
 // unoccluded ray only marks its (light, slot) state; k_accumulate then adds
 // the contributions in the reference's order.
-template <bool EXACT, bool BOUNDED>
+// WIDE: the launch walks the 4-wide collapse of the tree (trace_wide.h); any-hit results do not depend on it.
+template <bool EXACT, bool BOUNDED, bool WIDE = false>
 __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_shadow(TraceScene ts, PathBuffers pb, ShadowQueue q, int n_lights,
                                                      const uint32_t* __restrict__ queue, const uint32_t* __restrict__ d_count,
                                                      TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
                                                      unsigned long long* __restrict__ ray_counter) {
-    __shared__ int32_t s_stack[RT_STACK_LDS * RT_TBLOCK];
-    __shared__ __attribute__((aligned(16))) char s_top[RT_TOP_BYTES];
-    const TopTree top = stage_top_tree(ts.nodes, ts.n_nodes, s_top);
+    static_assert(!(WIDE && EXACT), "the exact follow-up launch walks the binary tree");
+    __shared__ int32_t s_stack[(WIDE ? RT_WSTACK : RT_STACK_LDS) * RT_TBLOCK];
+    __shared__ __attribute__((aligned(16))) char s_top[WIDE ? RT_WTOP_BYTES : RT_TOP_BYTES];
+    const auto top = stage_top<WIDE>(ts, s_top);
     const uint32_t paths = *d_count;
     // work item j = (light j / paths, path-queue entry j % paths)
     const uint32_t count = EXACT ? work->n_deferred : paths * (uint32_t)q.n_trace;
@@ -1134,7 +1137,7 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_shadow(TraceScene ts,
         if (h.id1 < 0) q.state[entry(j, s)] = 2;
     };
     if constexpr (BOUNDED) {
-        trace_persistent<true, EXACT, true>(
+        trace_rays<true, EXACT, true, false>(
             ts, count, work, deferred, s_stack, top,
             [&](uint32_t j, f3& org, f3& dir, float& tfar) -> bool {
                 uint32_t s;
@@ -1147,7 +1150,7 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_shadow(TraceScene ts,
             },
             mark, make_probe([&](uint32_t j) -> bool { uint32_t s; return q.state[entry(j, s)] == 1; }));
     } else {
-        trace_persistent<true, EXACT, false>(
+        trace_rays<true, EXACT, false, false>(
             ts, count, work, deferred, s_stack, top,
             [&](uint32_t j, f3& org, f3& dir) -> bool {
                 uint32_t s;
@@ -1167,15 +1170,17 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_shadow(TraceScene ts,
 // this bounce)) are both ready once k_shade
 // has run, so they share one persistent launch: item j < n_next is a
 // closest-hit ray, the others are shadow rays.
-template <bool EXACT>
+// WIDE: on the 4-wide tree; the closest-hit rays are then tie-tolerant (trace_wide.h).
+template <bool EXACT, bool WIDE = false>
 __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_bounce(TraceScene ts, PathBuffers pb, ShadowQueue q, int n_lights,
                                                                  const uint32_t* __restrict__ queue, const uint32_t* __restrict__ d_count,
                                                                  const uint32_t* __restrict__ d_next_count, TraceWork* __restrict__ work,
                                                                  uint32_t* __restrict__ deferred,
                                                                  unsigned long long* __restrict__ ray_counter) {
-    __shared__ int32_t s_stack[RT_STACK_LDS * RT_TBLOCK];
-    __shared__ __attribute__((aligned(16))) char s_top[RT_TOP_BYTES];
-    const TopTree top = stage_top_tree(ts.nodes, ts.n_nodes, s_top);
+    static_assert(!(WIDE && EXACT), "the exact follow-up launch walks the binary tree");
+    __shared__ int32_t s_stack[(WIDE ? RT_WSTACK : RT_STACK_LDS) * RT_TBLOCK];
+    __shared__ __attribute__((aligned(16))) char s_top[WIDE ? RT_WTOP_BYTES : RT_TOP_BYTES];
+    const auto top = stage_top<WIDE>(ts, s_top);
     const uint32_t paths = *d_count, n_next = *d_next_count;
     const uint32_t count = EXACT ? work->n_deferred : n_next + paths * (uint32_t)q.n_trace;
     const size_t n = pb.n, cap = q.cap;
@@ -1190,7 +1195,7 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_bounce(TraceScene ts,
         s = queue ? queue[e] : e;
         return (size_t)q.trace_lights[li] * n + s;
     };
-    trace_persistent<false, EXACT, false, true>(
+    trace_rays<false, EXACT, false, true>(
         ts, count, work, deferred, s_stack, top,
         [&](uint32_t j, f3& org, f3& dir, float& tfar, bool& any) -> bool {
             if (j < n_next) {   // path j of the next bounce

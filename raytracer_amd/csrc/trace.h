@@ -76,6 +76,9 @@ struct TraceScene {
     uint32_t ovf_stride;   // threads in the persistent grid
     uint32_t ovf_levels;
     int32_t tame;          // every box coordinate is finite and below 1e30 in magnitude
+    const float4* wnodes;  // 4-wide collapse of the same tree: 8 float4 per node (wide_bvh.h), breadth-first
+    int32_t n_wnodes;
+    int32_t wroot;         // 0, or the root's leaf link when the tree is a single triangle
 };
 
 // src/scene/Ray.cpp:17-34

@@ -14,7 +14,8 @@ from raytracer_amd import Context, scenes, api  # noqa: E402
 W, H = 1920, 1080
 n = W * H
 s = scenes.sponza_class()
-ctx = Context(s, W, H, max_depth=8, seed=0)
+WIDE = "--wide" in sys.argv
+ctx = Context(s, W, H, max_depth=8, seed=0, wide_bvh=WIDE)
 sets = {"coherent": scenes.camera_rays_numpy(s.camera, W, H), "incoherent": scenes.incoherent_rays(s, n, seed=0x5EED),
         "bounce": scenes.bounce_rays(s, W, H, n, seed=0x5EED, device=0)}
 sets["all"] = np.ascontiguousarray(np.concatenate([sets[k] for k in ("coherent", "incoherent", "bounce")], axis=1))

@@ -11,7 +11,7 @@ mode=$1; shift
 if [ "$mode" = build ]; then
   for spec in "$@"; do
     name=${spec%%:*}; flags=${spec#*:}
-    (mkdir -p $V/obj_$name && cd $R/raytracer_amd/csrc && make -s lbvh_host.o lbvh_device.o && make -s OBJ=$V/obj_$name OUT=$V/librt_$name.so EXTRA="$flags" $V/librt_$name.so) &
+    (mkdir -p $V/obj_$name && cd $R/raytracer_amd/csrc && make -s lbvh_host.o lbvh_device.o wide_bvh.o rt_node.o && make -s OBJ=$V/obj_$name OUT=$V/librt_$name.so EXTRA="$flags" $V/librt_$name.so) &
   done
   wait
   ls -la $V
