@@ -45,6 +45,42 @@ def algorithmic_valu_ops(n_rays: int, n_inner: int, n_tri: int) -> float:
     return 12.0 * n_rays + 54.0 * n_inner + 57.0 * n_tri
 
 
+def classify_against_oracle(orc, rays, gpu_t, gpu_id1, ref_t, ref_id1, threads):
+    """How a closest-hit result differs from the oracle's, by class: same distance and another id on a ray where two
+    or more reachable triangles lie at exactly that distance (an exact tie: the strict `<` of src/scene/BVH.cpp:139
+    keeps the first visited); another distance within 4 ulp whose triangle the reference's own test places exactly
+    there (a near tie: the triangle found first culls the other's box); anything else."""
+    bad_t = gpu_t.view(np.uint32) != ref_t.view(np.uint32)
+    bad_id = gpu_id1 != ref_id1
+    out = {"id_mismatches": int(bad_id.sum()), "dist_bit_mismatches": int(bad_t.sum()), "id_mismatches_on_exact_ties": 0,
+           "near_ties": 0, "id_mismatches_outside_ties": 0, "unexplained": 0}
+    idx = np.nonzero(bad_t | bad_id)[0]
+    if idx.size == 0:
+        return out
+    sub = np.ascontiguousarray(rays[:, idx])
+    tied = orc.intersect_ties(sub, threads=threads).astype(bool)
+    ct, _, _, ok = orc.check_candidates(sub, gpu_id1[idx])
+    genuine = (ok == 3) & (ct.view(np.uint32) == gpu_t[idx].view(np.uint32))
+    ulps = np.abs(gpu_t[idx].view(np.int32).astype(np.int64) - ref_t[idx].view(np.int32).astype(np.int64))
+    exact = ~bad_t[idx] & tied & genuine
+    near = bad_t[idx] & (ulps <= 4) & genuine
+    out["id_mismatches_on_exact_ties"] = int(exact.sum())
+    out["near_ties"] = int(near.sum())
+    out["id_mismatches_outside_ties"] = int((bad_id[idx] & ~exact & ~near).sum())
+    out["unexplained"] = int((~exact & ~near).sum())
+    return out
+
+
+def strong_scaling_fields(world: int, sharded) -> dict:
+    """Top-level keys of an N > 1 line beside `value` (weak scaling: every GPU traces ray sets of its own): the
+    tile-sharded 4K film of the same run, gather included, is the strong-scaling number."""
+    if world <= 1 or not sharded:
+        return {}
+    return {"value_strong": sharded["samples_per_sec"], "unit_strong": "samples/s", "samples_per_sec_strong": sharded["samples_per_sec"],
+            "scaling_of": {"value": "weak", "value_strong": "strong"},
+            "strong_workload": sharded["workload"]}
+
+
 def cpu_model() -> str:
     try:
         for line in open("/proc/cpuinfo"):
@@ -125,6 +161,14 @@ def main():
     W, H = args.width, args.height
     scene = scenes.sponza_class()
     ctx = Context(scene, W, H, max_depth=args.render_depth, seed=0, device=local_rank, wide_bvh=(args.bvh == "wide"))
+    # the other tree: timed after the headline for comparison; the path-tracing leg runs on the binary tree (exact films)
+    other_name = "binary" if args.bvh == "wide" else "wide"
+    compare = not args.no_set_diagnostics
+    xctx = None
+    if compare or (args.bvh == "wide" and args.render_passes > 0):
+        xctx = Context(scene, W, H, max_depth=args.render_depth, seed=0, device=local_rank, wide_bvh=(other_name == "wide"))
+    bctx = ctx if args.bvh == "binary" else xctx     # binary tree
+    wctx = ctx if args.bvh == "wide" else xctx       # 4-wide tree (None when not built)
     n = W * H
     coherent = scenes.camera_rays_numpy(scene.camera, W, H)
     incoherent = scenes.incoherent_rays(scene, n, seed=0x5EED + rank)
@@ -179,30 +223,75 @@ def main():
                               out_f[1].data_ptr(), out_f[2].data_ptr(), 5)
         set_ms[k] = ctx.last_trace_ms()
 
+    # the same launch on the other tree (outside the timed region)
+    other_ms, other_id1, other_t = float("nan"), None, None
+    if compare and xctx is not None:
+        xctx.trace_closest_dev(NS * n, d_both.data_ptr(), out_f[0].data_ptr(), out_i[0].data_ptr(), out_i[1].data_ptr(),
+                               out_f[1].data_ptr(), out_f[2].data_ptr(), max(args.warmup, 1))
+        xctx.trace_closest_dev(NS * n, d_both.data_ptr(), out_f[0].data_ptr(), out_i[0].data_ptr(), out_i[1].data_ptr(),
+                               out_f[1].data_ptr(), out_f[2].data_ptr(), max(args.steps, 1))
+        other_ms = xctx.last_trace_ms()
+        other_id1 = out_i[1].cpu().numpy().copy()
+        other_t = out_f[0].cpu().numpy().copy()
+
     # ---- path-tracing leg: samples/s at 1920x1080 (BASELINE.json configs[2] shape)
     render = None
     if args.render_passes > 0:
-        ctx.set_camera(scene.camera)
-        ctx.render(args.render_passes)  # warm-up
-        ctx.reset_accumulation()
-        s0 = ctx.stats()
+        rctx = bctx
+        rctx.set_camera(scene.camera)
+        rctx.render(args.render_passes)  # warm-up; fills the per-camera cache (primary hits, point-light visibility)
+        rctx.reset_accumulation()
+        s0 = rctx.stats()
         barrier()
+        rctx.synchronize()
         r0 = time.perf_counter()
-        ctx.render(args.render_passes)
+        rctx.render(args.render_passes)
+        rctx.synchronize()
         barrier()
         r_el = time.perf_counter() - r0
         if use_dist:
             t = torch.tensor([r_el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             r_el = float(t.item())
-        s1 = ctx.stats()
+        s1 = rctx.stats()
         traced = (s1["closest_rays"] - s0["closest_rays"]) + (s1["shadow_rays"] - s0["shadow_rays"])
         render = {
-            "workload": f"sponza_class {W}x{H}, depth {args.render_depth}, point+env NEE, {args.render_passes} passes per GPU",
+            "workload": f"sponza_class {W}x{H}, depth {args.render_depth}, point+env NEE, {args.render_passes} passes per GPU, still "
+                        "camera: the per-camera cache is warm (primary rays and point-light shadow rays of the primary vertex "
+                        "are not re-traced)",
+            "bvh": "binary (bit-exact hit ids, films identical to the oracle's)",
             "samples_per_sec": W * H * args.render_passes * world / r_el,
             "mrays_per_sec": traced * world / r_el / 1e6,
+            "traced_rays_per_pass": traced / args.render_passes,
             "ms_per_pass": r_el / args.render_passes * 1e3,
         }
+        # what a host that moves the camera every frame pays: the first pass after a camera change fills the cache
+        import copy
+        cam2 = copy.deepcopy(scene.camera)
+        cam2.pos = (np.asarray(cam2.pos, np.float32) + np.float32(1e-3)).astype(np.float32)
+        firsts = []
+        for rep in range(3):
+            rctx.set_camera(cam2 if rep % 2 == 0 else scene.camera)
+            rctx.synchronize()
+            f0 = time.perf_counter()
+            rctx.render(1)
+            rctx.synchronize()
+            firsts.append((time.perf_counter() - f0) * 1e3)
+        render["ms_first_pass_after_camera_change"] = float(np.median(firsts))
+        rctx.set_camera(scene.camera)
+        if wctx is not None:
+            wctx.set_camera(scene.camera)
+            wctx.render(args.render_passes)
+            wctx.reset_accumulation()
+            wctx.synchronize()
+            w0 = time.perf_counter()
+            wctx.render(args.render_passes)
+            wctx.synchronize()
+            render["wide_tree_ms_per_pass"] = (time.perf_counter() - w0) / args.render_passes * 1e3
+            rctx.reset_accumulation()
+            rctx.render(args.render_passes)
+            fw, fb = wctx.read_film(), rctx.read_film()
+            render["wide_tree_pixels_differing_from_binary"] = int((fw.view(np.uint32) != fb.view(np.uint32)).any(-1).sum())
 
     # ---- tile-sharded leg (BASELINE.json configs[3] shape): ONE film split over the ranks by interleaved tiles,
     # no exchange while rendering, one all-gather of the tile slabs over RCCL at read-out.  Strong scaling.  Part of
@@ -273,21 +362,30 @@ def main():
         counts = {}
         cpu_s = 0.0
         cpu_reps = 3  # about 20 CPU-seconds at 16 threads
-        parity = {"rays": NS * n, "id_mismatches": 0, "dist_bit_mismatches": 0, "per_set": {}}
+        parity = {"rays": NS * n, "bvh": args.bvh, "id_mismatches": 0, "dist_bit_mismatches": 0, "id_mismatches_on_exact_ties": 0,
+                  "near_ties": 0, "id_mismatches_outside_ties": 0, "unexplained": 0, "exact_distance_ties": 0, "per_set": {}}
+        parity_other = None if other_id1 is None else {"rays": NS * n, "bvh": other_name, "id_mismatches": 0, "dist_bit_mismatches": 0,
+                                                         "id_mismatches_on_exact_ties": 0, "near_ties": 0,
+                                                         "id_mismatches_outside_ties": 0, "unexplained": 0}
         for j, k in enumerate(sets):
             for rep in range(cpu_reps):
                 c0 = time.perf_counter()
                 rt, rid0, rid1, ru, rv, cnt = orc.intersect(sets[k], counters=True, threads=threads)
                 cpu_s += time.perf_counter() - c0
             counts[k] = cnt
-            bad_id = int((rid1 != gpu_id1[j * n:(j + 1) * n]).sum())
-            bad_t = int((rt.view(np.uint32) != gpu_t[j * n:(j + 1) * n].view(np.uint32)).sum())
-            parity["per_set"][k] = {"id_mismatches": bad_id, "dist_bit_mismatches": bad_t, "hit_fraction": float((rid1 >= 0).mean()),
-                                    # triangle tests that tied the held hit exactly (first-visited wins on both sides)
-                                    "exact_distance_ties": int(cnt["n_ties"])}
-            parity["exact_distance_ties"] = parity.get("exact_distance_ties", 0) + int(cnt["n_ties"])
-            parity["id_mismatches"] += bad_id
-            parity["dist_bit_mismatches"] += bad_t
+            sl = slice(j * n, (j + 1) * n)
+            cls = classify_against_oracle(orc, sets[k], gpu_t[sl], gpu_id1[sl], rt, rid1, threads)
+            # triangle tests of the oracle's own traversal that tied the held hit exactly (first-visited wins on both sides)
+            cls["exact_distance_ties"] = int(cnt["n_ties"])
+            cls["hit_fraction"] = float((rid1 >= 0).mean())
+            parity["per_set"][k] = cls
+            for key in ("id_mismatches", "dist_bit_mismatches", "id_mismatches_on_exact_ties", "near_ties", "id_mismatches_outside_ties",
+                        "unexplained", "exact_distance_ties"):
+                parity[key] += cls[key]
+            if parity_other is not None:
+                clo = classify_against_oracle(orc, sets[k], other_t[sl], other_id1[sl], rt, rid1, threads)
+                for key in clo:
+                    parity_other[key] += clo[key]
         cpu_baseline = {"value": cpu_reps * NS * n / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
                         "cpu_model": cpu_model(), "cores_available": len(os.sched_getaffinity(0)),
                         "sample": f"the full ray sets ({NS*n} rays) x {cpu_reps}, oracle closest hit, {threads} threads, {cpu_s:.1f} s wall"}
@@ -303,15 +401,40 @@ def main():
             # full-size film parity: one pass of the GPU tracer against one pass of the oracle with its transcendentals
             # switched to the polynomials the kernels restate ("shared" mode), compared bit for bit
             from oracle import binding as oracle_binding
-            ctx.reset_accumulation()
-            ctx.render(1)
-            g_film = ctx.read_film()
+            bctx.reset_accumulation()
+            bctx.render(1)
+            g_film = bctx.read_film()
             oracle_binding.set_math("shared")
             o_film, _ = orc.render(scene.camera, rw, rh, args.render_depth, 0, 1, threads=threads)
             oracle_binding.set_math("libm")
             same = (g_film.view(np.uint32) == o_film.view(np.uint32)) | (np.isnan(g_film) & np.isnan(o_film))
             render["film_parity"] = {"passes": 1, "pixels": rw * rh, "bit_identical": bool(same.all()),
                                      "pixels_differing": int((~same).any(-1).sum())}
+            # Roofline of a sample pass: the reference's algorithm on the rays of ONE pass (the oracle's integrator counts
+            # the node visits and triangle tests of its closest-hit and shadow rays) as fp32 lane-operations, over the
+            # time of a pass (all kernels of the pass: traversal, shading, accumulation), against the fp32 vector rate.
+            # A still camera lets the tracer keep the camera rays and the point-light shadow rays of the primary
+            # vertex from the pass before (they are the same rays): the steady-state figure leaves their work out of
+            # the numerator; the first pass after a camera change traces everything.
+            r_rays = rc["closest"] + rc["shadow"]
+            r_inner = rc["closest_inner"] + rc["shadow_inner"]
+            r_tri = rc["closest_tri"] + rc["shadow_tri"]
+            ops_all = algorithmic_valu_ops(r_rays, r_inner, r_tri)
+            ops_steady = algorithmic_valu_ops(r_rays - rc["prim_rays"] - rc["prim_point_rays"], r_inner - rc["prim_inner"] - rc["prim_point_inner"],
+                                              r_tri - rc["prim_tri"] - rc["prim_point_tri"])
+            t_pass = render["ms_per_pass"] * 1e-3
+            render["roofline"] = {
+                "bound": "valu", "unit": "T lane-ops/s", "peak": VALU_PEAK_TOPS,
+                "achieved": ops_steady / t_pass / 1e12, "frac": ops_steady / t_pass / 1e12 / VALU_PEAK_TOPS,
+                "ops_per_pass": ops_steady, "ops_per_pass_with_cached_rays": ops_all,
+                "oracle_counts_per_pass": rc,
+                "first_pass_after_camera_change": {"achieved": ops_all / (render["ms_first_pass_after_camera_change"] * 1e-3) / 1e12,
+                                                   "frac": ops_all / (render["ms_first_pass_after_camera_change"] * 1e-3) / 1e12 / VALU_PEAK_TOPS,
+                                                   "note": "one pass traced alone (batch of 1): every launch of the pass pays its drain"},
+                "note": "12 per ray + 54 per inner visit + 57 per triangle test, rays of one pass as the oracle's integrator traces them "
+                        "(the tracer skips rays whose result cannot change the film: the last bounce's extension ray and shadow rays "
+                        "with zero contribution); denominator = ms_per_pass, every kernel of the pass; the traversal launches' share "
+                        "of a pass is in profiles/r03/render_kernel_stats.csv"}
         n_inner = sum(counts[k]["n_inner"] for k in counts)
         n_tri = sum(counts[k]["n_tri"] for k in counts)
         tot_bytes = algorithmic_bytes(NS * n, n_inner, n_tri)
@@ -337,7 +460,7 @@ def main():
                                            "valu_instructions_per_ray", "rocprof_avg_launch_us") if k in tj}
             counters["source"] = "profiles/traffic.json: " + tj.get("source", "")
         cand = {
-            "valu": {"achieved": tot_ops / secs / 1e12, "peak": VALU_PEAK_TOPS, "unit": "TFLOP/s",
+            "valu": {"achieved": tot_ops / secs / 1e12, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
                      "frac": tot_ops / secs / 1e12 / VALU_PEAK_TOPS, "ops_per_launch": tot_ops,
                      "note": "fp32 lane-operations (no FMA: the path may not contract); 54 per inner visit, 57 per triangle "
                              "test, 12 per ray; peak = 256 CUs x 4 SIMD-32 x 2.4 GHz"},
@@ -352,7 +475,7 @@ def main():
             cand["l1_address_path"] = {"frac": counters.get("ta_busy"), "note": "TA_TA_BUSY / cycles of the profiled launch"}
         binding = max(("valu", "hbm"), key=lambda k: cand[k]["frac"])
         b = cand[binding]
-        roofline = {"bound": binding, "kernel": "k_trace_closest", "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"],
+        roofline = {"bound": binding, "kernel": "k_trace_closest_wide" if args.bvh == "wide" else "k_trace_closest<false>", "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"],
                     "frac": b["frac"], "traffic": traffic, "candidates": cand, "counters": counters,
                     "per_visit_byte_model": {"bytes_per_launch": tot_bytes, "gbs": tot_bytes / secs / 1e9,
                                              "over_hbm_peak": tot_bytes / secs / 1e9 / HBM_PEAK_GBS,
@@ -366,15 +489,20 @@ def main():
                                     "launched_alone_mrays_per_sec": n / set_ms[k] / 1e3} for k in counts}}
 
     line = {
-        "kernel_ms": {"all_sets_one_launch": float(np.mean(kernel_ms)), **{k + "_alone": v for k, v in set_ms.items()}},
+        "kernel_ms": {"all_sets_one_launch": float(np.mean(kernel_ms)), **{k + "_alone": v for k, v in set_ms.items()},
+                      "all_sets_one_launch_" + other_name + "_tree": other_ms},
         "metric": "Mrays/sec (closest-hit, whole node)", "value": mrays, "unit": "Mrays/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"primary-ray closest hit, sponza_class ({scene.n_triangles} triangles) {W}x{H}: "
                                f"coherent + incoherent + bounce sets of {n} rays each per GPU per step, one launch",
-                   "rays_per_step": rays_per_step, "bvh": "reference LBVH, 1 triangle per leaf"},
-        "roofline": roofline, "cpu_baseline": cpu_baseline, "sharded_render": sharded, "parity": parity, "render": render,
+                   "rays_per_step": rays_per_step,
+                   "bvh": "reference LBVH, 1 triangle per leaf" + (", collapsed to 4-wide nodes (same triangles reachable; ids may differ "
+                                                                   "only where triangles tie in distance: see parity)" if args.bvh == "wide" else "")},
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "sharded_render": sharded, "parity": parity,
+        "parity_" + other_name + "_tree": parity_other if not args.no_cpu_baseline else None, "render": render,
     }
+    line.update(strong_scaling_fields(world, sharded))
     sys.stdout.flush()
     with os.fdopen(json_fd, "w") as out:
         out.write(json.dumps(line) + "\n")

@@ -86,6 +86,10 @@ def lib():
     L.orc_bvh_nodes.argtypes = [vp, fp, ip, ip, ip, ip, ip]
     L.orc_intersect.argtypes = [vp, C.c_uint64, fp, fp, ip, ip, fp, fp, u64p, C.c_int]
     L.orc_occluded.argtypes = [vp, C.c_uint64, fp, ip, u64p]
+    L.orc_intersect_ties.argtypes = [vp, C.c_uint64, fp, C.POINTER(C.c_uint8), C.c_int]
+    L.orc_intersect_ties.restype = None
+    L.orc_check_candidates.argtypes = [vp, C.c_uint64, fp, ip, fp, fp, fp, C.POINTER(C.c_uint8)]
+    L.orc_check_candidates.restype = None
     L.orc_brute_force.argtypes = [vp, C.c_uint64, fp, fp, ip]
     L.orc_render.argtypes = [vp, fp, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, fp, u64p,
                              C.c_int, fp]
@@ -206,6 +210,26 @@ class OracleScene:
             return t, id0, id1, u, v, {"n_inner": cnt[0], "n_tri": cnt[1], "n_rays": cnt[2], "n_inner_stale": cnt[3], "n_ties": cnt[4]}
         return t, id0, id1, u, v
 
+    def intersect_ties(self, rays, threads=1):
+        """uint8 per ray: 1 when two or more reachable triangles lie at exactly the distance of the closest hit (the id the
+        strict `<` of src/scene/BVH.cpp:139 keeps then depends on the visiting order)."""
+        rays = np.ascontiguousarray(rays, np.float32)
+        n = rays.shape[1]
+        flags = np.empty(n, np.uint8)
+        self._L.orc_intersect_ties(self._h, n, _f(rays), flags.ctypes.data_as(C.POINTER(C.c_uint8)), threads)
+        return flags
+
+    def check_candidates(self, rays, id1):
+        """For hits another visiting order reported: (t, u, v, ok) of the reference's triangle test on triangle id1[i];
+        ok bit 0 = the test passes with t > 1e-4, bit 1 = every box from the root to the triangle's leaf passes."""
+        rays = np.ascontiguousarray(rays, np.float32)
+        id1 = np.ascontiguousarray(id1, np.int32)
+        n = rays.shape[1]
+        t = np.empty(n, np.float32); u = np.empty(n, np.float32); v = np.empty(n, np.float32)
+        ok = np.empty(n, np.uint8)
+        self._L.orc_check_candidates(self._h, n, _f(rays), _i(id1), _f(t), _f(u), _f(v), ok.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return t, u, v, ok
+
     def occluded(self, rays):
         rays = np.ascontiguousarray(rays, np.float32)
         n = rays.shape[1]
@@ -231,11 +255,13 @@ class OracleScene:
         """duv: optional (H, W, 4) float32 array receiving dUVx, dUVy of each primary hit."""
         if film is None:
             film = np.zeros((H, W, 4), np.float32)
-        cnt = (C.c_uint64 * 2)()
+        cnt = (C.c_uint64 * 12)()
         c = cam.packed()
         self._L.orc_render(self._h, _f(c), W, H, max_depth, seed, first_pass, n_passes, threads, _f(film), cnt, tile_size,
                             None if duv is None else _f(duv))
-        return film, {"closest": cnt[0], "shadow": cnt[1]}
+        keys = ("closest", "shadow", "closest_inner", "closest_tri", "shadow_inner", "shadow_tri", "prim_rays", "prim_inner", "prim_tri",
+                "prim_point_rays", "prim_point_inner", "prim_point_tri")
+        return film, {k: int(cnt[i]) for i, k in enumerate(keys)}
 
     def bounce_rays(self, cam, W, H, n, depth=0, max_depth=4, seed=0, threads=8):
         """(6, n) f32: bounce rays leaving the `depth`-th shaded vertex, gathered pass by pass until n are found."""

@@ -1234,6 +1234,12 @@ struct Scene {
 
 struct RenderCounters {
     std::atomic<uint64_t> closest{0}, shadow{0};
+    // node visits and triangle tests of those rays (the Counters of BVH::intersect / BVH::occluded summed), and, of
+    // them, the share of the rays that are the same in every pass for a still camera: the camera rays
+    // (src/cpu/PathTracer.cpp:43-53 has no jitter) and the shadow rays from the primary vertex towards point lights
+    // (PointLight::sampleLi ignores its random numbers, src/lights/PointLight.cpp:14-18)
+    std::atomic<uint64_t> closestInner{0}, closestTri{0}, shadowInner{0}, shadowTri{0};
+    std::atomic<uint64_t> primRays{0}, primInner{0}, primTri{0}, primPointRays{0}, primPointInner{0}, primPointTri{0};
 };
 
 // Test/bench hook: records the bounce ray each pixel traces after its
@@ -1299,7 +1305,8 @@ inline void shadePixel(const Scene& s, int x, int y, int W, int maxDepth, uint64
     const int L = (int)s.lights.size();
     const uint32_t pixel = (uint32_t)(y * W + x);
     float* out4 = film + (size_t)pixel * 4;
-    uint64_t nClosest = 0, nShadow = 0;
+    uint64_t nClosest = 0, nShadow = 0, nPrimPoint = 0;
+    Counters cClosest, cShadow, cPrimPoint;
     vec3 out = -ray.dir;
     vec3 pixelColor{0.f, 0.f, 0.f};
     vec3 threshold{1.f, 1.f, 1.f};
@@ -1313,7 +1320,9 @@ inline void shadePixel(const Scene& s, int x, int y, int W, int maxDepth, uint64
             vec3 li = light.sampleLi(vertex, u, in, lightPdf, &tmax);
             if (lightPdf == 0.0f) continue;
             nShadow++;
-            RayHit shadowHit = s.bvh.occluded(Ray(vertex.pos, in), nullptr, tmax);
+            const bool primPoint = d == 0 && light.isDelta();
+            if (primPoint) nPrimPoint++;
+            RayHit shadowHit = s.bvh.occluded(Ray(vertex.pos, in), rc ? (primPoint ? &cPrimPoint : &cShadow) : nullptr, tmax);
             if (shadowHit.status) continue;
             vec3 bsdfColor = bsdf.f(out, in);
             float bsdfPdf = bsdf.pdf(out, in);
@@ -1349,7 +1358,7 @@ inline void shadePixel(const Scene& s, int x, int y, int W, int maxDepth, uint64
             cap->flags[pixel] = 1;
         }
         nClosest++;
-        RayHit hit = s.bvh.intersect(ray);
+        RayHit hit = s.bvh.intersect(ray, rc ? &cClosest : nullptr);
         if (hit.status) {
             vertex = s.bvh.postIntersect(ray, hit, s.haveFrame);
             bsdf = computeBSDF(s, vertex, hit.id0);
@@ -1367,7 +1376,12 @@ inline void shadePixel(const Scene& s, int x, int y, int W, int maxDepth, uint64
     } else {
         out4[0] = pixelColor.x; out4[1] = pixelColor.y; out4[2] = pixelColor.z; out4[3] = 1.0f;
     }
-    if (rc) { rc->closest += nClosest; rc->shadow += nShadow; }
+    if (rc) {
+        rc->closest += nClosest; rc->shadow += nShadow;
+        rc->closestInner += cClosest.n_inner; rc->closestTri += cClosest.n_tri;
+        rc->shadowInner += cShadow.n_inner + cPrimPoint.n_inner; rc->shadowTri += cShadow.n_tri + cPrimPoint.n_tri;
+        rc->primPointRays += nPrimPoint; rc->primPointInner += cPrimPoint.n_inner; rc->primPointTri += cPrimPoint.n_tri;
+    }
 }
 
 // PathTracer::computeTile, src/cpu/PathTracer.cpp:17-164: 2x2 pixel quads,
@@ -1395,8 +1409,12 @@ inline void computeTile(const Scene& s, const Camera& cam, int startX, int start
                     int x = xBlock + xB;
                     if (x >= W) break;
                     Ray r = cameraRay(cam, x, y, W, H);
-                    RayHit hit = s.bvh.intersect(r);
-                    if (rc) rc->closest += 1;
+                    Counters cPrim;
+                    RayHit hit = s.bvh.intersect(r, rc ? &cPrim : nullptr);
+                    if (rc) {
+                        rc->closest += 1; rc->closestInner += cPrim.n_inner; rc->closestTri += cPrim.n_tri;
+                        rc->primRays += 1; rc->primInner += cPrim.n_inner; rc->primTri += cPrim.n_tri;
+                    }
                     int id = yB * 2 + xB;
                     statusBlock[id] = hit.status;
                     if (hit.status) {

@@ -125,6 +125,83 @@ void orc_intersect(const orc_scene* o, uint64_t n, const float* rays, float* t, 
     }
 }
 
+// Per-ray tie flag, independent of any visiting order: flags[i] = 1 when at least two triangles that the recursion
+// can reach (every box from the root to the leaf passes intersectBBox, src/scene/Ray.cpp:17-34) pass the triangle
+// test (src/scene/Ray.cpp:36-67) with dist > 1e-4 at exactly the distance of the closest hit.  The strict `<` of
+// src/scene/BVH.cpp:139 then keeps whichever of them is visited first, so the reported id depends on the order
+// (the reference's own traversal may never test the second one: its box is culled once the first is held).
+void orc_intersect_ties(const orc_scene* o, uint64_t n, const float* rays, uint8_t* flags, int threads) {
+    const float *ox = rays, *oy = rays + n, *oz = rays + 2 * n, *dx = rays + 3 * n, *dy = rays + 4 * n,
+                *dz = rays + 5 * n;
+    if (threads < 1) threads = 1;
+    const BVH& b = o->s.bvh;
+    auto work = [&](int th) {
+        uint64_t lo = n * th / threads, hi = n * (th + 1) / threads;
+        std::vector<int> stack;
+        for (uint64_t i = lo; i < hi; ++i) {
+            flags[i] = 0;
+            Ray r({ox[i], oy[i], oz[i]}, {dx[i], dy[i], dz[i]});
+            const RayHit h = b.intersect(r);
+            if (!h.status) continue;
+            int at_min = 0;
+            stack.clear();
+            if (intersectBBox(r, b.nodes[b.rootId].box).status) stack.push_back((int)b.rootId);
+            while (!stack.empty() && at_min < 2) {
+                const BVHNode& nd = b.nodes[stack.back()];
+                stack.pop_back();
+                if (nd.isLeaf) {
+                    if (nd.tri < 0) continue;
+                    const RayHit tst = intersectTriangle(r, b.vertices[b.indices[nd.tri]].pos, b.vertices[b.indices[nd.tri + 1]].pos,
+                                                         b.vertices[b.indices[nd.tri + 2]].pos);
+                    if (tst.status && tst.dist > 0.0001f && tst.dist == h.dist) ++at_min;
+                } else {
+                    if (intersectBBox(r, b.nodes[nd.left].box).status) stack.push_back(nd.left);
+                    if (intersectBBox(r, b.nodes[nd.right].box).status) stack.push_back(nd.right);
+                }
+            }
+            flags[i] = at_min >= 2 ? 1 : 0;
+        }
+    };
+    if (threads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int i = 0; i < threads; ++i) pool.emplace_back(work, i);
+        for (auto& th : pool) th.join();
+    }
+}
+
+// Checks candidate hits another traversal order reported: for ray i and the triangle whose first index sits at
+// id1[i] (skipped when negative), the reference's own triangle test (src/scene/Ray.cpp:36-67) gives t, u, v, and
+// ok[i] gets bit 0 when that test passes with t > 1e-4 (the acceptance of src/scene/BVH.cpp:139 without the
+// distance compare) and bit 1 when the boxes of all nodes from the root to the triangle's leaf pass
+// intersectBBox (src/scene/Ray.cpp:17-34), i.e. when the recursion could reach the triangle at all.
+void orc_check_candidates(const orc_scene* o, uint64_t n, const float* rays, const int32_t* id1, float* t, float* u, float* v,
+                          uint8_t* ok) {
+    const BVH& b = o->s.bvh;
+    const size_t NN = b.nodes.size();
+    std::vector<int> parent(NN, -1);
+    std::vector<int> leaf_of(b.indices.size() / 3, -1);
+    for (size_t k = 0; k < NN; ++k) {
+        const BVHNode& nd = b.nodes[k];
+        if (nd.isLeaf) { if (nd.tri >= 0) leaf_of[nd.tri / 3] = (int)k; }
+        else { parent[nd.left] = (int)k; parent[nd.right] = (int)k; }
+    }
+    const float *ox = rays, *oy = rays + n, *oz = rays + 2 * n, *dx = rays + 3 * n, *dy = rays + 4 * n,
+                *dz = rays + 5 * n;
+    for (uint64_t i = 0; i < n; ++i) {
+        t[i] = std::numeric_limits<float>::infinity(); u[i] = v[i] = 0.f; ok[i] = 0;
+        if (id1[i] < 0 || (size_t)id1[i] + 2 >= b.indices.size() + 0 || id1[i] % 3) continue;
+        Ray r({ox[i], oy[i], oz[i]}, {dx[i], dy[i], dz[i]});
+        const uint32_t i0 = b.indices[id1[i]], i1 = b.indices[id1[i] + 1], i2 = b.indices[id1[i] + 2];
+        RayHit h = intersectTriangle(r, b.vertices[i0].pos, b.vertices[i1].pos, b.vertices[i2].pos);
+        t[i] = h.dist; u[i] = h.bc.y; v[i] = h.bc.z;
+        if (h.status && h.dist > 0.0001f) ok[i] |= 1;
+        bool reach = true;
+        for (int k = leaf_of[id1[i] / 3]; k >= 0 && reach; k = parent[k]) reach = intersectBBox(r, b.nodes[k].box).status;
+        if (reach && leaf_of[id1[i] / 3] >= 0) ok[i] |= 2;
+    }
+}
+
 // 0 = libm (default), 1 = the fixed single-precision polynomials the HIP kernels restate (bit-comparable films).
 // Process-wide; not to be switched while a render is running.
 void orc_set_math(int mode) { mathMode() = mode ? 1 : 0; }
@@ -199,7 +276,7 @@ void orc_brute_force(const orc_scene* o, uint64_t n, const float* rays, float* t
 
 // camera: pos, right, up, forward (12 floats).  Renders passes
 // [first_pass, first_pass+n_passes) into film (W*H*4 floats, read-modify-write).
-// ray_counts[2] = {closest-hit rays, shadow rays} (may be null).
+// ray_counts[12] (may be null): see the end of the function.
 void orc_render(const orc_scene* o, const float* camera, int W, int H, int max_depth, uint64_t seed,
                 uint32_t first_pass, uint32_t n_passes, int threads, float* film, uint64_t* ray_counts, int tile_size,
                 float* duv_out /* W*H*4 or null: dUVx, dUVy of each primary hit (last pass), untouched where it missed */) {
@@ -212,7 +289,14 @@ void orc_render(const orc_scene* o, const float* camera, int W, int H, int max_d
     for (uint32_t p = 0; p < n_passes; ++p)
         renderPass(o->s, cam, W, H, max_depth, seed, first_pass + p, (float)(first_pass + p), film, threads,
                    ray_counts ? &rc : nullptr, tile_size > 0 ? tile_size : 64, duv_out);
-    if (ray_counts) { ray_counts[0] = rc.closest; ray_counts[1] = rc.shadow; }
+    if (ray_counts) {
+        // [0..1] rays, [2..5] node visits / triangle tests of the closest-hit and of the shadow rays, [6..11] of those, the
+        // camera rays and the shadow rays from the primary vertex towards point lights (rays, visits, tests each)
+        ray_counts[0] = rc.closest; ray_counts[1] = rc.shadow;
+        ray_counts[2] = rc.closestInner; ray_counts[3] = rc.closestTri; ray_counts[4] = rc.shadowInner; ray_counts[5] = rc.shadowTri;
+        ray_counts[6] = rc.primRays; ray_counts[7] = rc.primInner; ray_counts[8] = rc.primTri;
+        ray_counts[9] = rc.primPointRays; ray_counts[10] = rc.primPointInner; ray_counts[11] = rc.primPointTri;
+    }
 }
 
 // Camera rays of src/cpu/PathTracer.cpp:43-52 for the whole film, row-major.
