@@ -126,6 +126,7 @@ struct rt_ctx {
     uint32_t* d_counts_init = nullptr;  // template copied in at the start of a pass
     uint32_t n_counts = 0;
     ShadowQueue sq{};                      // shadow entries of the bounce being resolved
+    ShadeArgs* d_shade_args = nullptr;     // [2]: k_shade's parameter blocks with path-state buffer 0 / 1 as the current one
     int32_t* d_light_list = nullptr;       // [L] all lights, then [n_uncached] the lights without cached primary visibility
     int n_uncached_lights = 0;
     uint32_t* d_pass_deferred_b = nullptr; // deferred list of the shadow launches
@@ -445,11 +446,11 @@ int run_pass(rt_ctx* c, uint32_t nb) {
         pbd.rays = c->d_rays[cur]; pbd.beta = c->d_beta[cur]; pbd.slot = c->d_slot[cur];
         pbd.rays_next = c->d_rays[cur ^ 1]; pbd.beta_next = c->d_beta[cur ^ 1]; pbd.slot_next = c->d_slot[cur ^ 1];
         if (c->any_glossy)
-            hipLaunchKernelGGL(k_shade<true>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, prime, seed_mixed, pass, qin, cnt_in,
-                               cnt_out, c->sq, c->d_raystats + 1);
+            hipLaunchKernelGGL(k_shade<true>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, c->d_shade_args + cur, d, D, prime, seed_mixed, pass, qin,
+                               cnt_in, cnt_out, c->d_raystats + 1);
         else
-            hipLaunchKernelGGL(k_shade<false>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, pbd, c->ss, d, D, prime, seed_mixed, pass, qin, cnt_in,
-                               cnt_out, c->sq, c->d_raystats + 1);
+            hipLaunchKernelGGL(k_shade<false>, dim3(gshade), dim3(RT_BLOCK), 0, c->stream, c->d_shade_args + cur, d, D, prime, seed_mixed, pass, qin,
+                               cnt_in, cnt_out, c->d_raystats + 1);
         TraceWork* w = work + d;
         // the shadow entries this bounce's traversal launch walks (at bounce 0 the cached ones are already resolved)
         ShadowQueue sqd = c->sq;
@@ -985,6 +986,18 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         if ((r = dev_alloc(c, &c->d_pass_deferred_b, cap + n))) return r;
     }
     c->path_state_bytes = c->device_bytes - bytes_before_state;
+    {
+        // k_shade's parameter blocks, one per choice of the current path-state buffer (run_pass swaps them every bounce)
+        ShadeArgs sa[2];
+        for (int k = 0; k < 2; ++k) {
+            sa[k].pb = c->pb;
+            sa[k].pb.rays = c->d_rays[k]; sa[k].pb.beta = c->d_beta[k]; sa[k].pb.slot = c->d_slot[k];
+            sa[k].pb.rays_next = c->d_rays[k ^ 1]; sa[k].pb.beta_next = c->d_beta[k ^ 1]; sa[k].pb.slot_next = c->d_slot[k ^ 1];
+            sa[k].sc = c->ss;
+            sa[k].sq = c->sq;
+        }
+        if ((r = dev_upload(c, &c->d_shade_args, sa, 2))) return r;
+    }
     if ((r = dev_alloc(c, &c->d_work, 1))) return r;
     if ((r = dev_alloc(c, &c->d_raystats, 4))) return r;
     HIP_TRY(c, hipMemset(c->d_raystats, 0, 4 * sizeof(unsigned long long)));

@@ -865,12 +865,23 @@ struct ShadowQueue {
 // writes the film (it does so once: nothing about it changes until the camera moves) and the shadow rays towards
 // point lights are traced, their outcome then being copied to pb.prim_vis by k_cache_visibility; with prime == 0
 // that outcome is taken from the cache and no such ray is queued.
+//
+// The three parameter blocks (about 85 dwords) come through one pointer to device memory instead of by value: as
+// kernel arguments they were all fetched into scalar registers up front and spilled from there; through the pointer
+// each field is a scalar load where it is used.
+struct ShadeArgs {
+    PathBuffers pb;
+    ShadeScene sc;
+    ShadowQueue sq;
+};
 template <bool GLOSSY>
-__global__ __launch_bounds__(RT_BLOCK) void k_shade(PathBuffers pb, ShadeScene sc, int depth, int max_depth, int prime, uint64_t seed_mixed,
+__global__ __launch_bounds__(RT_BLOCK) void k_shade(const ShadeArgs* __restrict__ args, int depth, int max_depth, int prime, uint64_t seed_mixed,
                                                     uint32_t first_pass, const uint32_t* __restrict__ queue,
                                                     const uint32_t* __restrict__ d_count, uint32_t* __restrict__ next_count,
-                                                    ShadowQueue sq,
                                                     unsigned long long* __restrict__ shadow_ray_counter) {
+    const PathBuffers& pb = args->pb;
+    const ShadeScene& sc = args->sc;
+    const ShadowQueue& sq = args->sq;
     __shared__ uint32_t s_cnt[RT_BLOCK / 64 + 1];
     __shared__ float4 s_marg[RT_MARG_LDS];
     const uint32_t count = *d_count;
