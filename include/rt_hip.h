@@ -113,7 +113,8 @@ typedef struct rt_params {
     uint32_t flags;        /* rt_flags; 0 = defaults */
     uint32_t batch;        /* passes rt_render traces together as one wavefront (more rays per launch;
                               path state grows with it: 144 B per pixel slot and 41 B per slot and light, 45 B
-                              with area lights); 0 -> 32, limited by a 64 GiB budget.  The film is
+                              with area lights); 0 -> 32, limited by a budget of 64 GiB or 60 % of the device's free memory
+                              (rt_stats.batch reports what was chosen).  The film is
                               the one that many separate passes leave, bit for bit. */
 } rt_params;
 
@@ -271,10 +272,12 @@ uint32_t rt_morton3d(float x, float y, float z);
  * src/app/App.cpp:40 makes one integrator).  Replaces the tile pool of Integrator::update
  * (src/cpu/Integrator.cpp:33-49: 16 threads pulling 64x64 tiles) by n_devices GPUs, device i taking the tiles
  * t % n_devices == i, and Integrator::sync (src/cpu/Integrator.cpp:21-24) by a gather of the devices' tile slabs:
- * one RCCL communicator per device (ncclCommInitAll), one grouped ncclAllGather over xGMI, one scatter kernel on
- * the first device.  The scene is replicated; params->device, rank and world are ignored (set per device).
+ * one RCCL communicator per device (ncclCommInitAll), one group of ncclSend / ncclRecv pairs over xGMI towards the
+ * first device (RT_NODE_GATHER=allgather in the environment: one grouped ncclAllGather instead), one scatter kernel
+ * there.  The scene is replicated; params->device, rank and world are ignored (set per device).
  * Every context renders on a host thread of its own inside rt_node_render.  RCCL is loaded at run time
- * (librccl.so.1, or the path in RT_RCCL_LIB); RT_ERR_NO_DEVICE if it cannot be. */
+ * (librccl.so.1, or only the path in RT_RCCL_LIB when that is set), before anything is allocated; RT_ERR_NO_DEVICE
+ * if it cannot be. */
 typedef struct rt_node rt_node;
 int rt_node_create(const rt_scene_desc* scene, const rt_params* params, const int32_t* devices, int32_t n_devices, rt_node** out);
 void rt_node_destroy(rt_node* node);
@@ -290,7 +293,12 @@ int rt_node_render(rt_node* node, uint32_t n_passes);
 /* Gathers the film on the first device; *d_film_out = width*height*4 floats of device memory owned by the node
  * (row-major, y = 0 at the top), valid until the next gather. */
 int rt_node_gather_film(rt_node* node, const float** d_film_out);
-/* rt_node_gather_film + copy to host: the whole film, width*height*4 floats. */
+/* rt_node_gather_film + copy to host, replacing Integrator::sync's source (src/cpu/Integrator.cpp:21-24):
+ * *host_film_out = the whole film, width*height*4 floats, in pinned host memory owned by the node (allocated at the
+ * first call), valid until the next rt_node_map_film / rt_node_read_film.  A host that only uploads the film to its
+ * own staging buffer reads it from here without another copy. */
+int rt_node_map_film(rt_node* node, const float** host_film_out);
+/* rt_node_map_film + memcpy into caller memory: the whole film, width*height*4 floats. */
 int rt_node_read_film(rt_node* node, float* rgba_out);
 /* Device time of the last all-gather (HIP events on the first device's stream). */
 float rt_node_last_gather_ms(const rt_node* node);

@@ -80,7 +80,7 @@ EXPORTS = [
     "rt_read_primary_duv", "rt_trace_occluded_bounded", "rt_read_last_bounce_rays", "rt_trace_closest_noalloc",
     "rt_node_create", "rt_node_destroy", "rt_node_last_error", "rt_node_device_count", "rt_node_context", "rt_node_set_camera",
     "rt_node_reset_accumulation", "rt_node_render", "rt_node_gather_film", "rt_node_read_film", "rt_node_last_gather_ms",
-    "rt_get_wide_bvh",
+    "rt_get_wide_bvh", "rt_node_map_film",
 ]
 
 
@@ -144,6 +144,7 @@ def load_library():
     lib.rt_node_render.argtypes = [vp, C.c_uint32]
     lib.rt_node_gather_film.argtypes = [vp, C.POINTER(vp)]
     lib.rt_node_read_film.argtypes = [vp, fp]
+    lib.rt_node_map_film.argtypes = [vp, C.POINTER(vp)]
     lib.rt_node_last_gather_ms.argtypes = [vp]
     lib.rt_node_last_gather_ms.restype = C.c_float
     for name in EXPORTS:
@@ -399,6 +400,13 @@ class Node:
         out = np.empty((self.height, self.width, 4), np.float32)
         self._check(self._lib.rt_node_read_film(self._h, _fptr(out)))
         return out
+
+    def map_film(self) -> np.ndarray:
+        """The gathered film as a (H, W, 4) view of the node's pinned host buffer (valid until the next read-out)."""
+        ptr = C.c_void_p()
+        self._check(self._lib.rt_node_map_film(self._h, C.byref(ptr)))
+        buf = (C.c_float * (self.height * self.width * 4)).from_address(ptr.value)
+        return np.frombuffer(buf, np.float32).reshape(self.height, self.width, 4)
 
     def gather_film_device(self) -> int:
         """Device pointer (first device) of the gathered width*height*4 film."""

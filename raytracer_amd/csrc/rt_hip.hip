@@ -892,8 +892,8 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         }
     }
     c->n_valid = (uint32_t)q0.size();
-    // ---- passes traced together: as many as asked for (default 32) within a
-    // path-state budget of 64 GiB and 32-bit entry indices
+    // ---- passes traced together: as many as asked for (default 32) within the
+    // path-state budget and 32-bit entry indices
     {
         const uint64_t L1 = (uint64_t)std::max<uint32_t>(1, sd->n_lights);
         // bytes of path state per slot (rays, beta and slot ids twice; hit; L; vertex; status; pixel id; queue entry;
@@ -902,7 +902,13 @@ static int create_impl(rt_ctx* c, const rt_scene_desc* sd, const rt_params* pr) 
         const uint64_t per_slot = 144 + (41 + (c->any_area ? 4 : 0)) * L1;
         uint64_t S = pr->batch ? pr->batch : 32;
         const uint64_t one = std::max<uint64_t>(1, (uint64_t)c->n_slots);
-        S = std::min<uint64_t>(S, std::max<uint64_t>(1, (64ull << 30) / (per_slot * one)));
+        // budget: 64 GiB, or 60 % of what is free on the device right now when that is less (other contexts may
+        // share the GPU); the batch only changes speed, never the film
+        uint64_t budget = 64ull << 30;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<uint64_t>(budget, (uint64_t)free_b / 10 * 6);
+        else (void)hipGetLastError();
+        S = std::min<uint64_t>(S, std::max<uint64_t>(1, budget / (per_slot * one)));
         S = std::min<uint64_t>(S, std::max<uint64_t>(1, 0x7FFFFFFFull / (L1 * one)));
         S = std::min<uint64_t>(S, 64);
         c->batch = (uint32_t)S;

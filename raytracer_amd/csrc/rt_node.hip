@@ -1,8 +1,10 @@
 // One process driving several GPUs of a node (declared in include/rt_hip.h, rt_node_*): the scene is replicated
 // on every device, the film is sharded by interleaved tiles (rank i of n on device i: the GPU form of the
 // reference's tile pool, src/cpu/Integrator.cpp:33-49), every device renders its tiles on a host thread of its
-// own, and at read-out the tile slabs are all-gathered with RCCL (one communicator per device, ncclCommInitAll,
-// one grouped ncclAllGather) and scattered into the film on the first device.
+// own (persistent workers), and at read-out the tile slabs are gathered with RCCL on the first device -- one
+// communicator per device (ncclCommInitAll), one group of ncclSend / ncclRecv pairs, so every slab crosses xGMI once
+// (RT_NODE_GATHER=allgather selects one grouped ncclAllGather instead, which leaves the slabs on every device) -- and
+// scattered into the film there.  The film reaches the host through a pinned buffer the node owns.
 //
 // RCCL is bound at run time (dlopen of librccl.so.1): the library then carries no link-time dependency on a
 // particular RCCL build, and a process that already holds one (PyTorch ships its own) shares it.
@@ -11,8 +13,12 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -32,18 +38,32 @@ struct Rccl {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
+// RT_RCCL_LIB, when set, is the only library tried; otherwise the usual names.
 bool load_rccl(Rccl& r, std::string& err) {
-    const char* names[] = {getenv("RT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
-        if (!n || !*n) continue;
+    const char* forced = getenv("RT_RCCL_LIB");
+    const char* usual[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string why;
+    auto try_open = [&](const char* n) {
         r.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (r.handle) break;
+        if (!r.handle) {
+            const char* e = dlerror();   // one call: it returns the text and clears it
+            why = e ? e : "not found";
+        }
+        return r.handle != nullptr;
+    };
+    if (forced && *forced) {
+        try_open(forced);
+    } else {
+        for (const char* n : usual)
+            if (try_open(n)) break;
     }
     if (!r.handle) {
-        err = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "not found");
+        err = std::string("cannot load RCCL (") + ((forced && *forced) ? forced : "librccl.so.1") + "): " + why;
         return false;
     }
     auto sym = [&](const char* s) { return dlsym(r.handle, s); };
@@ -52,13 +72,72 @@ bool load_rccl(Rccl& r, std::string& err) {
     r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(sym("ncclGroupStart"));
     r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(sym("ncclGroupEnd"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(sym("ncclAllGather"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(sym("ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(sym("ncclRecv"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-    if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.AllGather || !r.GetErrorString) {
+    if (!r.CommInitAll || !r.CommDestroy || !r.GroupStart || !r.GroupEnd || !r.AllGather || !r.Send || !r.Recv || !r.GetErrorString) {
         err = "the RCCL library lacks an expected entry point";
+        dlclose(r.handle);
+        r.handle = nullptr;
         return false;
     }
     return true;
 }
+
+// One host thread per device, alive as long as the node: rt_node_render is called once per sample pass by the host
+// adapter, and starting and joining threads at that rate costs more than the hand-over.
+class Workers {
+public:
+    explicit Workers(int n) : jobs_(n), rc_(n, 0), state_(n, 0) {
+        for (int i = 0; i < n; ++i) threads_.emplace_back([this, i]() { loop(i); });
+    }
+    ~Workers() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    // runs fn(i) on worker i for every i and waits for all of them
+    void run(const std::function<int(int)>& fn, std::vector<int>& rc) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            for (size_t i = 0; i < jobs_.size(); ++i) { jobs_[i] = fn; state_[i] = 1; }
+        }
+        cv_.notify_all();
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&]() { for (int s : state_) if (s != 0) return false; return true; });
+        rc = rc_;
+    }
+
+private:
+    void loop(int i) {
+        for (;;) {
+            std::function<int(int)> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&]() { return stop_ || state_[i] == 1; });
+                if (stop_) return;
+                job = jobs_[i];
+                state_[i] = 2;
+            }
+            const int r = job(i);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                rc_[i] = r;
+                state_[i] = 0;
+            }
+            done_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::vector<std::function<int(int)>> jobs_;
+    std::vector<int> rc_, state_;   // state: 0 idle, 1 posted, 2 running
+    std::vector<std::thread> threads_;
+    bool stop_ = false;
+};
 
 thread_local std::string g_node_create_error;
 
@@ -71,8 +150,11 @@ struct rt_node {
     std::vector<rt_ctx*> ctx;
     std::vector<hipStream_t> streams;     // one per device, for the slab copy and the gather
     std::vector<float*> d_local;          // this device's slab, padded to per_rank floats
-    std::vector<float*> d_gathered;       // n * per_rank floats per device
+    std::vector<float*> d_gathered;       // n * per_rank floats: on devices[0] only, or on every device in all-gather mode
+    bool allgather = false;               // RT_NODE_GATHER=allgather
     float* d_film = nullptr;              // width * height * 4 floats on devices[0]
+    float* h_film = nullptr;              // the same size, pinned host memory (allocated at the first read-out)
+    Workers* workers = nullptr;           // one thread per device when n > 1
     uint64_t per_rank = 0;                // floats
     Rccl rccl;
     std::vector<ncclComm_t> comms;
@@ -101,17 +183,14 @@ namespace {
         }                                                                                               \
     } while (0)
 
-// Runs fn(i) for every device on a thread of its own and returns the first non-zero status.
+// Runs fn(i) for every device on that device's worker thread and returns the first non-zero status.
 template <typename F>
 int for_each_device(rt_node* nd, F fn) {
     std::vector<int> rc(nd->n, RT_OK);
-    if (nd->n == 1) {
-        rc[0] = fn(0);
+    if (nd->n == 1 || !nd->workers) {
+        for (int i = 0; i < nd->n; ++i) rc[i] = fn(i);
     } else {
-        std::vector<std::thread> th;
-        th.reserve(nd->n);
-        for (int i = 0; i < nd->n; ++i) th.emplace_back([&, i]() { rc[i] = fn(i); });
-        for (auto& t : th) t.join();
+        nd->workers->run(fn, rc);
     }
     for (int i = 0; i < nd->n; ++i)
         if (rc[i] != RT_OK) {
@@ -133,6 +212,10 @@ int node_create_impl(rt_node* nd, const rt_scene_desc* scene, const rt_params* p
                 nd->err = "a device is listed twice";
                 return RT_ERR_ARG;
             }
+    // RCCL first: without it nothing below is of use, and nothing has been allocated yet
+    if (!load_rccl(nd->rccl, nd->err)) return RT_ERR_NO_DEVICE;
+    const char* gm = getenv("RT_NODE_GATHER");
+    nd->allgather = gm && std::string(gm) == "allgather";
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         (void)hipGetLastError();
@@ -168,15 +251,16 @@ int node_create_impl(rt_node* nd, const rt_scene_desc* scene, const rt_params* p
         NODE_HIP(nd, hipStreamCreateWithFlags(&nd->streams[i], hipStreamNonBlocking));
         NODE_HIP(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_local[i]), nd->per_rank * sizeof(float)));
         NODE_HIP(nd, hipMemset(nd->d_local[i], 0, nd->per_rank * sizeof(float)));   // the padding behind a short slab stays zero
-        NODE_HIP(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_gathered[i]), (size_t)n * nd->per_rank * sizeof(float)));
+        if (i == 0 || nd->allgather)
+            NODE_HIP(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_gathered[i]), (size_t)n * nd->per_rank * sizeof(float)));
     }
     NODE_HIP(nd, hipSetDevice(devices[0]));
     NODE_HIP(nd, hipMalloc(reinterpret_cast<void**>(&nd->d_film), (size_t)nd->width * nd->height * 4 * sizeof(float)));
     NODE_HIP(nd, hipEventCreate(&nd->ev0));
     NODE_HIP(nd, hipEventCreate(&nd->ev1));
-    if (!load_rccl(nd->rccl, nd->err)) return RT_ERR_NO_DEVICE;
     nd->comms.assign(n, nullptr);
     NODE_NCCL(nd, nd->rccl.CommInitAll(nd->comms.data(), n, nd->devices.data()));
+    if (n > 1) nd->workers = new Workers(n);
     return RT_OK;
 }
 
@@ -188,6 +272,8 @@ const char* rt_node_last_error(const rt_node* nd) { return nd ? nd->err.c_str() 
 
 void rt_node_destroy(rt_node* nd) {
     if (!nd) return;
+    delete nd->workers;
+    nd->workers = nullptr;
     for (int i = 0; i < nd->n; ++i) {
         if (i >= (int)nd->ctx.size() || !nd->ctx[i]) continue;   // create stopped before this device
         (void)hipSetDevice(nd->devices[i]);
@@ -197,9 +283,10 @@ void rt_node_destroy(rt_node* nd) {
         if (i < (int)nd->d_gathered.size() && nd->d_gathered[i]) (void)hipFree(nd->d_gathered[i]);
         if (i < (int)nd->ctx.size() && nd->ctx[i]) rt_destroy(nd->ctx[i]);
     }
-    if (nd->d_film || nd->ev0 || nd->ev1) {
+    if (nd->d_film || nd->h_film || nd->ev0 || nd->ev1) {
         (void)hipSetDevice(nd->devices[0]);
         if (nd->d_film) (void)hipFree(nd->d_film);
+        if (nd->h_film) (void)hipHostFree(nd->h_film);
         if (nd->ev0) (void)hipEventDestroy(nd->ev0);
         if (nd->ev1) (void)hipEventDestroy(nd->ev1);
     }
@@ -259,16 +346,36 @@ int rt_node_gather_film(rt_node* nd, const float** d_film_out) {
     if (r != RT_OK) return r;
     NODE_HIP(nd, hipSetDevice(nd->devices[0]));
     NODE_HIP(nd, hipEventRecord(nd->ev0, nd->streams[0]));
-    NODE_NCCL(nd, nd->rccl.GroupStart());
-    for (int i = 0; i < n; ++i) {
-        ncclResult_t g = nd->rccl.AllGather(nd->d_local[i], nd->d_gathered[i], nd->per_rank, kNcclFloat, nd->comms[i], nd->streams[i]);
-        if (g != 0) {
-            (void)nd->rccl.GroupEnd();
-            nd->err = std::string("ncclAllGather failed: ") + nd->rccl.GetErrorString(g);
-            return RT_ERR_HIP;
+    if (nd->allgather) {
+        NODE_NCCL(nd, nd->rccl.GroupStart());
+        for (int i = 0; i < n; ++i) {
+            ncclResult_t g = nd->rccl.AllGather(nd->d_local[i], nd->d_gathered[i], nd->per_rank, kNcclFloat, nd->comms[i], nd->streams[i]);
+            if (g != 0) {
+                (void)nd->rccl.GroupEnd();
+                nd->err = std::string("ncclAllGather failed: ") + nd->rccl.GetErrorString(g);
+                return RT_ERR_HIP;
+            }
+        }
+        NODE_NCCL(nd, nd->rccl.GroupEnd());
+    } else {
+        // gather on the presenting device only: its own slab by a device copy, every other slab by one
+        // ncclSend / ncclRecv pair (rank i of the communicator = device i)
+        NODE_HIP(nd, hipMemcpyAsync(nd->d_gathered[0], nd->d_local[0], nd->per_rank * sizeof(float), hipMemcpyDeviceToDevice, nd->streams[0]));
+        if (n > 1) {
+            NODE_NCCL(nd, nd->rccl.GroupStart());
+            ncclResult_t g = 0;
+            for (int i = 1; i < n && g == 0; ++i) {
+                g = nd->rccl.Recv(nd->d_gathered[0] + (size_t)i * nd->per_rank, nd->per_rank, kNcclFloat, i, nd->comms[0], nd->streams[0]);
+                if (g == 0) g = nd->rccl.Send(nd->d_local[i], nd->per_rank, kNcclFloat, 0, nd->comms[i], nd->streams[i]);
+            }
+            if (g != 0) {
+                (void)nd->rccl.GroupEnd();
+                nd->err = std::string("ncclSend / ncclRecv failed: ") + nd->rccl.GetErrorString(g);
+                return RT_ERR_HIP;
+            }
+            NODE_NCCL(nd, nd->rccl.GroupEnd());
         }
     }
-    NODE_NCCL(nd, nd->rccl.GroupEnd());
     for (int i = 0; i < n; ++i) {
         NODE_HIP(nd, hipSetDevice(nd->devices[i]));
         NODE_HIP(nd, hipStreamSynchronize(nd->streams[i]));
@@ -284,12 +391,25 @@ int rt_node_gather_film(rt_node* nd, const float** d_film_out) {
     return RT_OK;
 }
 
-int rt_node_read_film(rt_node* nd, float* rgba_out) {
-    if (!nd || !rgba_out) return RT_ERR_ARG;
+int rt_node_map_film(rt_node* nd, const float** host_film_out) {
+    if (!nd || !host_film_out) return RT_ERR_ARG;
     int r = rt_node_gather_film(nd, nullptr);
     if (r != RT_OK) return r;
     NODE_HIP(nd, hipSetDevice(nd->devices[0]));
-    NODE_HIP(nd, hipMemcpy(rgba_out, nd->d_film, (size_t)nd->width * nd->height * 4 * sizeof(float), hipMemcpyDeviceToHost));
+    const size_t bytes = (size_t)nd->width * nd->height * 4 * sizeof(float);
+    if (!nd->h_film) NODE_HIP(nd, hipHostMalloc(reinterpret_cast<void**>(&nd->h_film), bytes, hipHostMallocDefault));
+    NODE_HIP(nd, hipMemcpyAsync(nd->h_film, nd->d_film, bytes, hipMemcpyDeviceToHost, nd->streams[0]));
+    NODE_HIP(nd, hipStreamSynchronize(nd->streams[0]));
+    *host_film_out = nd->h_film;
+    return RT_OK;
+}
+
+int rt_node_read_film(rt_node* nd, float* rgba_out) {
+    if (!nd || !rgba_out) return RT_ERR_ARG;
+    const float* h = nullptr;
+    int r = rt_node_map_film(nd, &h);
+    if (r != RT_OK) return r;
+    memcpy(rgba_out, h, (size_t)nd->width * nd->height * 4 * sizeof(float));
     return RT_OK;
 }
 

@@ -53,9 +53,17 @@ int main(int argc, char** argv) {
     sd.n_lights = hdr[3]; sd.lights = lights.data();
     const int W = atoi(argv[2]), H = atoi(argv[3]), frames = atoi(argv[4]);
     std::vector<int32_t> devices;
-    for (const char* p = argc > 6 ? argv[6] : "0"; *p;) {
-        devices.push_back((int32_t)strtol(p, const_cast<char**>(&p), 10));
-        if (*p == ',') ++p;
+    // comma-separated device ordinals; anything else ends the program instead of looping on text strtol cannot read
+    for (const char* p = argc > 6 ? argv[6] : "0";;) {
+        char* end = nullptr;
+        const long v = strtol(p, &end, 10);
+        if (end == p || v < 0 || (*end != ',' && *end != '\0')) {
+            fprintf(stderr, "demo_host: device list must be ordinals separated by commas (got \"%s\")\n", argc > 6 ? argv[6] : "0");
+            return 2;
+        }
+        devices.push_back((int32_t)v);
+        if (*end == '\0') break;
+        p = end + 1;
     }
     const bool use_node = argc > 7 && std::string(argv[7]) == "node";
     try {
