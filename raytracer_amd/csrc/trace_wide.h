@@ -19,7 +19,10 @@
 //    float below x: for operands that are not NaN this is (tmin <= tmax) && (tmax > 0) && (tmin < bound), the
 //    reference's three comparisons, as one.  Unused slots hold boxes at +inf, which fail it for every ray that
 //    passed the root test.
-//  * the four (key, link) pairs go through a 5-comparator sorting network, key = max(tmin, tiny) or +inf;
+//  * the near and far plane of each axis are fetched by per-ray offsets (the sign of the direction says which of
+//    a box's two planes is which), so the test needs no min/max per axis;
+//  * the four (key, link) pairs go through four comparators (nearest to position 0, farthest to 3), key =
+//    max(tmin, tiny) or +inf;
 //  * the traversal stack lives in LDS only, [level][thread], with a marker at the bottom: the three farther
 //    children are stored above the stack pointer unconditionally (entries that did not pass land above the
 //    new top and are overwritten later), the pointer advances by (children that passed) - 1, and a lane with no
@@ -38,10 +41,13 @@ namespace rt {
 #define RT_WSPILL 4         // entries moved to / from the global buffer at a time
 #endif
 // The LDS-resident top of the 4-wide tree: the first RT_WTOP_NODES nodes of the breadth-first array (what is left
-// of a workgroup's 80 KB beside the stack), each as the first 112 bytes of its record (six box planes and the
+// of a workgroup's LDS beside the stack), each as the first 112 bytes of its record (six box planes and the
 // links).  A record's planes sit at the same offsets as in global memory, so one set of per-ray plane offsets
 // serves both; the stride of 28 dwords spreads random nodes over all sixteen 16-byte bank groups.
-#define RT_WTOP_NODES ((81920 - RT_WSTACK * RT_TBLOCK * 4) / 112)
+#ifndef RT_WLDS
+#define RT_WLDS 81920       // LDS bytes of a workgroup: half of a CU's 160 KB, two workgroups of 16 waves per CU
+#endif
+#define RT_WTOP_NODES ((RT_WLDS - RT_WSTACK * RT_TBLOCK * 4) / 112)
 #define RT_WTOP_BYTES (RT_WTOP_NODES * 112)
 struct WideTop {
     uint32_t base;   // LDS byte address of node 0
@@ -67,6 +73,9 @@ RT_DEV tr_f32x4 lds128(uint32_t addr) { return *(const RT_LDS tr_f32x4*)(uintptr
 #define RT_UNSPILL0 ((int32_t)0x80000002)   // bottom marker of a lane with spilled entries: RT_UNSPILL0 + their number
 #define RT_LEAF_LO ((int32_t)0xC0000000)    // leaf links (~slot) lie in [RT_LEAF_LO, -1]; the state codes lie below
 
+#ifndef RT_WLB_WAVES
+#define RT_WLB_WAVES RT_LB_WAVES
+#endif
 #ifndef RT_WLEAF_MIN
 #define RT_WLEAF_MIN 8
 #endif
@@ -250,6 +259,8 @@ RT_DEV void trace_wide(const TraceScene& sc, uint32_t count, TraceWork* work, ui
                         zn = lds128(a + nz + 32u); zf = lds128(a - nz + 80u);
                         lkf = lds128(a + 96u);
                     } else {
+                        // (computing the six addresses once for both homes of a node, LDS stride 112 and global stride
+                        // 128, needs seven more live registers: measured no faster even where they are free)
                         const uint32_t a = (uint32_t)cur << 7;   // < 4 GiB: checked by the host; cur >= 1 here (node 0 is in LDS)
                         const float4 a0 = ldb128(rs_nodes, a + nx), a3 = ldb128(rs_nodes, a - nx + 48u);
                         const float4 a1 = ldb128(rs_nodes, a + ny + 16u), a4 = ldb128(rs_nodes, a - ny + 64u);
@@ -334,7 +345,7 @@ RT_DEV void trace_wide(const TraceScene& sc, uint32_t count, TraceWork* work, ui
 
 // Closest hit over a ray set on the 4-wide tree (the batch form of BVH::intersect, tie-tolerant as described
 // above); the follow-up launch over the deferred list is k_trace_closest<true>.
-__global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_trace_closest_wide(TraceScene sc, const float* __restrict__ rays, uint32_t stride, uint32_t n,
+__global__ __launch_bounds__(RT_TBLOCK RT_WLB_WAVES) void k_trace_closest_wide(TraceScene sc, const float* __restrict__ rays, uint32_t stride, uint32_t n,
                                                                  TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
                                                                  float* __restrict__ o_t, int32_t* __restrict__ o_id0,
                                                                  int32_t* __restrict__ o_id1, float* __restrict__ o_u, float* __restrict__ o_v,
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_trace_closest_wide(Tr
 
 // Any hit over a ray set on the 4-wide tree (BVH::occluded; BOUNDED: with a far bound per ray).
 template <bool BOUNDED>
-__global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_trace_occluded_wide(TraceScene sc, const float* __restrict__ rays, const float* __restrict__ tmax,
+__global__ __launch_bounds__(RT_TBLOCK RT_WLB_WAVES) void k_trace_occluded_wide(TraceScene sc, const float* __restrict__ rays, const float* __restrict__ tmax,
                                                                   uint32_t stride, uint32_t n, TraceWork* __restrict__ work,
                                                                   uint32_t* __restrict__ deferred, int32_t* __restrict__ status) {
     __shared__ int32_t s_stack[RT_WSTACK * RT_TBLOCK];
@@ -406,7 +417,7 @@ RT_DEV void trace_rays(const TraceScene& sc, uint32_t count, TraceWork* work, ui
 }
 
 // k_extend (trace.h) on the 4-wide tree: closest hit for the slots a queue names.
-__global__ __launch_bounds__(RT_TBLOCK RT_LB_WAVES) void k_extend_wide(TraceScene sc, const float* __restrict__ rays, uint32_t stride,
+__global__ __launch_bounds__(RT_TBLOCK RT_WLB_WAVES) void k_extend_wide(TraceScene sc, const float* __restrict__ rays, uint32_t stride,
                                                           const uint32_t* __restrict__ queue, const uint32_t* __restrict__ d_count,
                                                           TraceWork* __restrict__ work, uint32_t* __restrict__ deferred,
                                                           float* __restrict__ o_t, int32_t* __restrict__ o_id0, int32_t* __restrict__ o_id1,
