@@ -45,6 +45,14 @@ def algorithmic_valu_ops(n_rays: int, n_inner: int, n_tri: int) -> float:
     return 12.0 * n_rays + 54.0 * n_inner + 57.0 * n_tri
 
 
+def algorithmic_valu_cycles(n_rays: int, n_inner: int, n_tri: int) -> float:
+    """SIMD cycles the same lane-operations take as full 64-lane wave instructions at the issue rates measured on
+    this chip (tools/ubench/inst_ubench, profiles/r03/inst_ubench.json: v_add/sub/mul_f32 2.5 cycles per wave
+    instruction, min/max/compare/select 4.2).  Per inner visit 24 subtract/multiply + 30 min/max/compare; per
+    triangle test 40 + 17; the 12 per ray (three divisions) at 4.2."""
+    return ((24.0 * 2.5 + 30.0 * 4.2) * n_inner + (40.0 * 2.5 + 17.0 * 4.2) * n_tri + 12.0 * 4.2 * n_rays) / 64.0
+
+
 def classify_against_oracle(orc, rays, gpu_t, gpu_id1, ref_t, ref_id1, threads):
     """How a closest-hit result differs from the oracle's, by class: same distance and another id on a ray where two
     or more reachable triangles lie at exactly that distance (an exact tie: the strict `<` of src/scene/BVH.cpp:139
@@ -450,14 +458,20 @@ def main():
         st = ctx.stats()
         tree_bytes = 64.0 * (st["n_triangles"] - 1) + 48.0 * st["n_triangles"]
         compulsory = 44.0 * NS * n + tree_bytes
+        headline_kernel = "k_trace_closest_wide" if args.bvh == "wide" else "k_trace_closest<false>"
         traffic = None
         counters = None   # pipe utilisation of the same kernel from committed rocprofv3 --pmc passes (not this run)
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp):
             tj = json.load(open(tp))
-            traffic = tj.get("k_trace_closest_bytes_per_launch")
-            counters = {k: tj[k] for k in ("tcc_hit_rate", "valu_issue_busy", "ta_busy", "valu_active_lane_fraction",
-                                           "valu_instructions_per_ray", "rocprof_avg_launch_us") if k in tj}
+            tj = tj.get(headline_kernel)
+        else:
+            tj = None
+        if tj:
+            traffic = tj.get("bytes_per_launch")
+            counters = {k: tj[k] for k in ("tcc_hit_rate", "valu_pipe_busy", "ta_busy", "valu_active_lane_fraction",
+                                           "valu_instructions_per_ray", "salu_instructions_per_ray", "simd_cycles_per_ray",
+                                           "rocprof_avg_launch_us") if k in tj}
             counters["source"] = "profiles/traffic.json: " + tj.get("source", "")
         cand = {
             "valu": {"achieved": tot_ops / secs / 1e12, "peak": VALU_PEAK_TOPS, "unit": "T lane-ops/s",
@@ -468,6 +482,13 @@ def main():
                     "frac": compulsory / secs / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": compulsory,
                     "note": "compulsory bytes: 44 B per ray + the node and triangle arrays once"},
         }
+        mix_cycles = algorithmic_valu_cycles(NS * n, n_inner, n_tri)
+        cand["valu_at_measured_issue_rates"] = {
+            "frac": mix_cycles / (1024.0 * 2.4e9 * secs), "simd_cycles_per_launch": mix_cycles,
+            "note": "diagnostic, not the headline: the same lane-operations as full wave instructions at the issue rates measured "
+                    "on this chip (add/sub/mul 2.5 cycles per wave instruction, min/max/compare/select 4.2; "
+                    "profiles/r03/inst_ubench.json) over the launch's 1024 SIMDs x 2.4 GHz x time; the `valu` candidate prices "
+                    "every operation at 2 cycles"}
         if traffic:
             cand["hbm_measured"] = {"achieved": traffic / (counters["rocprof_avg_launch_us"] * 1e-6) / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": traffic / (counters["rocprof_avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -475,7 +496,7 @@ def main():
             cand["l1_address_path"] = {"frac": counters.get("ta_busy"), "note": "TA_TA_BUSY / cycles of the profiled launch"}
         binding = max(("valu", "hbm"), key=lambda k: cand[k]["frac"])
         b = cand[binding]
-        roofline = {"bound": binding, "kernel": "k_trace_closest_wide" if args.bvh == "wide" else "k_trace_closest<false>", "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"],
+        roofline = {"bound": binding, "kernel": headline_kernel, "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"],
                     "frac": b["frac"], "traffic": traffic, "candidates": cand, "counters": counters,
                     "per_visit_byte_model": {"bytes_per_launch": tot_bytes, "gbs": tot_bytes / secs / 1e9,
                                              "over_hbm_peak": tot_bytes / secs / 1e9 / HBM_PEAK_GBS,

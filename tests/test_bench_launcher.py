@@ -1,4 +1,5 @@
 """bench.py's multi-GPU launcher (argument handling only; no GPU needed)."""
+import json
 import os
 import subprocess
 import sys
@@ -50,3 +51,19 @@ def test_launcher_starts_one_rank_per_gpu(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-5:] == [BENCH, "--gpus", "4", "--steps", "5"]
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_strong_scaling_keys_of_a_multi_gpu_line():
+    """An N > 1 line carries the strong-scaling number (the tile-sharded film of the same run) beside the weak-scaling
+    `value`, under keys of its own that say which is which; an N = 1 line, or a run without the sharded leg, has none."""
+    sys.path.insert(0, ROOT)
+    import bench
+    sharded = {"samples_per_sec": 1.5e9, "workload": "sponza_class 3840x2160, 8 passes, tiles of 64x64 dealt round-robin, film gathered on rank 0"}
+    assert bench.strong_scaling_fields(1, sharded) == {}
+    assert bench.strong_scaling_fields(4, None) == {}
+    f = bench.strong_scaling_fields(4, sharded)
+    assert f["value_strong"] == 1.5e9 and f["unit_strong"] == "samples/s" and f["samples_per_sec_strong"] == f["value_strong"]
+    assert f["scaling_of"] == {"value": "weak", "value_strong": "strong"}
+    assert f["strong_workload"] == sharded["workload"]
+    line = {"metric": "m", "value": 1.0, "scaling": "weak", **f}
+    assert json.loads(json.dumps(line))["value_strong"] == 1.5e9

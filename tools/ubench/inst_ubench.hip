@@ -16,6 +16,10 @@ __global__ __launch_bounds__(256) void k_inst(float* out, int iters, float c0, f
     float a[N], b[N];
 #pragma unroll
     for (int i = 0; i < N; ++i) { a[i] = (float)(threadIdx.x + i) * 1e-3f; b[i] = (float)(threadIdx.x * 3 + i) * 1e-3f; }
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 pa[N], pc = {c1, c1}, pd = {c0, c0};
+#pragma unroll
+    for (int i = 0; i < N; ++i) { pa[i].x = a[i]; pa[i].y = b[i]; }
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -31,10 +35,11 @@ __global__ __launch_bounds__(256) void k_inst(float* out, int iters, float c0, f
     if (KIND == 8) { asm volatile("v_cmp_lt_f32 s[40:41], %0, %1\n v_cndmask_b32 %0, %0, %1, s[40:41]" : "+v"(a[i]) : "v"(b[i]) : "s40", "s41"); } \
     if (KIND == 9) { asm volatile("v_addc_co_u32 %0, vcc, %0, 0, vcc\n v_addc_co_u32 %0, vcc, %0, 0, vcc" : "+v"(a[i]) : : "vcc"); } \
     if (KIND == 10) { asm volatile("v_lshl_add_u32 %0, %0, 7, %1\n v_and_or_b32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b[i]), "v"(c0)); } \
-    if (KIND == 11) { asm volatile("s_and_b64 s[40:41], s[40:41], vcc\n s_or_b64 s[42:43], s[42:43], vcc" : : : "s40", "s41", "s42", "s43"); } \
-    if (KIND == 12) { asm volatile("v_sub_f32 %0, %0, %1\n s_and_b64 s[40:41], s[40:41], vcc" : "+v"(a[i]) : "v"(c1) : "s40", "s41"); } \
     if (KIND == 13) { asm volatile("v_min_u32 %0, %0, %1\n v_max_u32 %0, %0, %2" : "+v"(a[i]) : "v"(b[i]), "v"(c0)); }            \
     if (KIND == 14) { asm volatile("v_cmp_lt_f32 vcc, %0, %1\n s_nop 1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b[i]) : "vcc"); } \
+    if (KIND == 16) { asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %0, %0, %1" : "+v"(pa[i]) : "v"(pc)); }             \
+    if (KIND == 17) { asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n v_pk_mul_f32 %0, %0, %2" : "+v"(pa[i]) : "v"(pc), "v"(pd)); } \
+    if (KIND == 18) { asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n v_pk_mul_f32 %0, %0, %2 op_sel_hi:[1,0]" : "+v"(pa[i]) : "v"(pc), "v"(pd)); } \
     if (KIND == 15) { asm volatile("v_mul_f32 %0, %0, %1\n v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c0)); }
             REP8(ONE)
 #undef ONE
@@ -42,7 +47,7 @@ __global__ __launch_bounds__(256) void k_inst(float* out, int iters, float c0, f
     }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < N; ++i) s += a[i];
+    for (int i = 0; i < N; ++i) s += a[i] + pa[i].x + pa[i].y;
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
@@ -90,8 +95,9 @@ int main() {
     run<8>(d_out, num_cu, "v_cmp -> sgpr + dependent v_cndmask", 2);
     run<9>(d_out, num_cu, "v_addc_co_u32 x2", 2);
     run<10>(d_out, num_cu, "v_lshl_add_u32 + v_and_or_b32", 2);
-    run<11>(d_out, num_cu, "s_and_b64 + s_or_b64", 2);
-    run<12>(d_out, num_cu, "v_sub_f32 + s_and_b64", 2);
+    run<16>(d_out, num_cu, "v_pk_mul_f32 x2 (two floats each)", 2);
+    run<17>(d_out, num_cu, "v_pk_add_f32(neg) + v_pk_mul_f32 (dependent pair, two floats each)", 2);
+    run<18>(d_out, num_cu, "v_pk_add_f32(neg, broadcast lo) + v_pk_mul_f32 (broadcast lo)", 2);
     printf(" {\"kind\": \"end\", \"cycles_per_wave_inst\": 0}]}\n");
     CK(hipFree(d_out));
     return 0;
