@@ -2,7 +2,8 @@
 collect it).  Runs the BASELINE.json configurations that fit one GPU and writes
 profiles/<tag>/configs.json: GPU time, CPU-oracle time on a bounded sample,
 and film agreement where both sides render the same passes.
-usage (on the GPU box): python tests/run_configs.py <out.json> [c1 c3 c4 c5]"""
+usage (on the GPU box): python tests/run_configs.py <out.json> [wide] [c1 c3 c4 c5 c5a tex n4]
+("wide": every context walks the 4-wide tree, RT_FLAG_WIDE_BVH)"""
 import json
 import os
 import sys
@@ -17,6 +18,7 @@ from oracle.binding import OracleScene  # noqa: E402
 from raytracer_amd import Context, scenes  # noqa: E402
 
 THREADS = max(1, min(16, len(os.sched_getaffinity(0))))
+WIDE = False
 
 
 def agree(film, ref):
@@ -31,7 +33,7 @@ def agree(film, ref):
 
 def gpu_render(scene, W, H, depth, spp, seed=0):
     t0 = time.perf_counter()
-    ctx = Context(scene, W, H, max_depth=depth, seed=seed)
+    ctx = Context(scene, W, H, max_depth=depth, seed=seed, wide_bvh=WIDE)
     setup = time.perf_counter() - t0
     ctx.set_camera(scene.camera)
     ctx.render(1)
@@ -68,8 +70,13 @@ def cpu_render(scene, W, H, depth, spp, seed=0):
 
 def main():
     out_path = sys.argv[1]
-    which = sys.argv[2:] or ["c1", "c3", "c4", "c5"]
-    out = {"cpu_threads": THREADS}
+    global WIDE
+    which = sys.argv[2:]
+    if "wide" in which:
+        WIDE = True
+        which.remove("wide")
+    which = which or ["c1", "c3", "c4", "c5"]
+    out = {"cpu_threads": THREADS, "bvh": "4-wide" if WIDE else "binary"}
     if "c1" in which:
         s = scenes.cornell_box()
         film, g = gpu_render(s, 512, 512, 4, 16)
