@@ -232,7 +232,8 @@ int rt_trace_occluded_dev(rt_ctx* ctx, uint32_t n, const float* d_rays_soa, int3
 /* rt_trace_closest_dev for callers that cannot allocate device memory (code
  * under HIP graph capture, tight serving loops, harnesses that forbid
  * hipMalloc): it has no counterpart in the reference.  Same inputs, outputs
- * and results as rt_trace_closest_dev with repeat = 1, but the launch's work
+ * and results as rt_trace_closest_dev with repeat = 1 (on the tree the context
+ * was created with, RT_FLAG_WIDE_BVH included), but the launch's work
  * counters and its list of rays for the exact follow-up launch live in a fixed
  * array inside the library (16 MiB + 1.25 KiB per device, held until the
  * process ends) instead of memory the context grows on demand, so the call

@@ -1256,8 +1256,12 @@ int rt_trace_closest_noalloc(rt_ctx* c, uint32_t n, const float* d_rays, float* 
     uint32_t* deferred = reinterpret_cast<uint32_t*>(c->scratch_ptr + kNoAllocWorkBytes);
     // the array keeps the last call's counters: they must start at zero (the list is rewritten before it is read)
     HIP_TRY(c, hipMemsetAsync(work, 0, sizeof(TraceWork), c->stream));
-    hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, work, deferred, d_t,
-                       d_id0, d_id1, d_u, d_v, c->d_raystats);
+    if (c->use_wide)   // the same tree rt_trace_closest_dev walks in this context
+        hipLaunchKernelGGL(k_trace_closest_wide, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, work, deferred, d_t,
+                           d_id0, d_id1, d_u, d_v, c->d_raystats);
+    else
+        hipLaunchKernelGGL(k_trace_closest<false>, dim3(grid_for(c, n)), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, work, deferred, d_t,
+                           d_id0, d_id1, d_u, d_v, c->d_raystats);
     hipLaunchKernelGGL(k_trace_closest<true>, dim3(c->grid_exact), dim3(RT_TBLOCK), 0, c->stream, c->ts, d_rays, n, n, work, deferred, d_t,
                        d_id0, d_id1, d_u, d_v, c->d_raystats);
     HIP_TRY(c, hipGetLastError());

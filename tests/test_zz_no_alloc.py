@@ -23,10 +23,13 @@ def _trace(ctx, fn, rays):
     return out_f.cpu().numpy().view(np.uint32), out_i.cpu().numpy()
 
 
-def test_noalloc_entry_point_matches_the_allocating_one():
+@pytest.mark.parametrize("wide", [False, True], ids=["binary_tree", "wide_tree"])
+def test_noalloc_entry_point_matches_the_allocating_one(wide):
+    """Both entry points walk the tree the context was made with (a ray's result does not depend on how the launch
+    is scheduled, on either tree, so the comparison is bit for bit on the 4-wide tree too)."""
     rng = np.random.default_rng(42)
     scene = _soup(rng, 20000, "plain")
-    ctx = Context(scene, 64, 64)
+    ctx = Context(scene, 64, 64, wide_bvh=wide)
     big = np.concatenate([_rays(rng, scene, 300_000), scenes.camera_rays_numpy(scene.camera, 640, 360)], axis=1)
     small = np.ascontiguousarray(_rays(rng, scene, 70_001)[:, ::-1])
     for rays in (big, small):          # two calls in a row, the second smaller
