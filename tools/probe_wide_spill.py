@@ -1,3 +1,5 @@
+"""Development check (needs a -DRT_PROBE build): runs the deep-tree GPU test of the 4-wide traversal and prints how many
+fix-up sections (LDS stack spill / refill) its launches executed, to confirm that the test exercises that path."""
 import ctypes as C, sys, numpy as np
 sys.path.insert(0, '.')
 import importlib.util
