@@ -220,12 +220,12 @@ class Context:
 
     def __init__(self, scene: Scene, width: int, height: int, max_depth: int = 4, seed: int = 0, device: int = 0,
                  rank: int = 0, world: int = 1, tile_size: int = 64, use_frame: bool = True, host_bvh: bool = False, batch: int = 0,
-                 wide_bvh: bool = False):
+                 wide_bvh=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.width, self.height, self.world, self.rank, self.tile_size = width, height, world, rank, tile_size
         d, self._keep = _scene_desc(scene, use_frame)
-        p = rt_params(width, height, max_depth, tile_size, seed, device, rank, world, (RT_FLAG_HOST_BVH if host_bvh else 0) | (RT_FLAG_WIDE_BVH if wide_bvh else 0), batch)
+        p = rt_params(width, height, max_depth, tile_size, seed, device, rank, world, (RT_FLAG_HOST_BVH if host_bvh else 0) | (RT_FLAG_WIDE_BVH if _want_wide(wide_bvh) else 0), batch)
         rc = self._lib.rt_create(C.byref(d), C.byref(p), C.byref(self._h))
         if rc != 0:
             raise RtError(rc, self._lib.rt_last_error(None).decode())
@@ -355,17 +355,25 @@ class Context:
         self._check(self._lib.rt_synchronize(self._h))
 
 
+def _want_wide(wide_bvh) -> bool:
+    """wide_bvh=None leaves the choice to the environment: RT_WIDE_BVH=1 makes every context that does not say
+    otherwise walk the 4-wide tree (RT_FLAG_WIDE_BVH); the default is the reference's binary tree."""
+    if wide_bvh is None:
+        return os.environ.get("RT_WIDE_BVH", "0").lower() in ("1", "true", "yes")
+    return bool(wide_bvh)
+
+
 class Node:
     """One rt_node: several GPUs of a node driven by this process, one film sharded over them by interleaved tiles
     and gathered with RCCL at read-out (rt_node_* of include/rt_hip.h)."""
 
     def __init__(self, scene: Scene, width: int, height: int, devices, max_depth: int = 4, seed: int = 0, tile_size: int = 64,
-                 use_frame: bool = True, batch: int = 0):
+                 use_frame: bool = True, batch: int = 0, wide_bvh=None):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.width, self.height, self.tile_size, self.devices = width, height, tile_size, list(devices)
         d, self._keep = _scene_desc(scene, use_frame)
-        p = rt_params(width, height, max_depth, tile_size, seed, 0, 0, 1, 0, batch)
+        p = rt_params(width, height, max_depth, tile_size, seed, 0, 0, 1, RT_FLAG_WIDE_BVH if _want_wide(wide_bvh) else 0, batch)
         devs = (C.c_int32 * len(self.devices))(*self.devices)
         rc = self._lib.rt_node_create(C.byref(d), C.byref(p), devs, len(self.devices), C.byref(self._h))
         if rc != 0:

@@ -38,13 +38,14 @@ class HipPathTracer {
     // film gathered over RCCL.  One device keeps to the single-context entry points.
     // (use_node = true takes the multi-device entry points for a single device too.)
     HipPathTracer(const rt_scene_desc& scene, int width, int height, const std::vector<int32_t>& devices, int max_depth = 4,
-                  uint64_t seed = 0, uint32_t passes_per_update = 1, bool use_node = false)
+                  uint64_t seed = 0, uint32_t passes_per_update = 1, bool use_node = false, uint32_t flags = 0)
         : _width(width), _height(height), _passes(passes_per_update ? passes_per_update : 1) {
         if (devices.empty()) throw std::runtime_error("HipPathTracer: no device given");
         rt_params p{};
         p.width = width; p.height = height; p.max_depth = max_depth; p.tile_size = 64;
         p.seed = seed; p.device = devices[0]; p.rank = 0; p.world = 1;
         p.batch = _passes;   // path state sized for what one update() traces
+        p.flags = flags;     // RT_FLAG_* of rt_hip.h (RT_FLAG_WIDE_BVH: faster traversal, tie-tolerant hit ids)
         if (devices.size() == 1 && !use_node) {
             if (rt_create(&scene, &p, &_ctx) != RT_OK) throw std::runtime_error(std::string("rt_create: ") + rt_last_error(nullptr));
         } else if (rt_node_create(&scene, &p, devices.data(), (int32_t)devices.size(), &_node) != RT_OK) {
