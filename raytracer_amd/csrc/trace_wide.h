@@ -293,12 +293,10 @@ RT_DEV void trace_wide(const TraceScene& sc, uint32_t count, TraceWork* work, ui
         const int32_t ln_ = sw_ ? (lb) : (la), lx_ = sw_ ? (la) : (lb);  \
         (ka) = kn_; (kb) = kx_; (la) = ln_; (lb) = lx_;                  \
     } while (0)
-#ifndef RT_WEXP_NOSORT
                     RT_CSWAP(k0, l0, k1, l1);
                     RT_CSWAP(k2, l2, k3, l3);
                     RT_CSWAP(k0, l0, k2, l2);
                     RT_CSWAP(k1, l1, k3, l3);
-#endif
 #undef RT_CSWAP
                     const bool v0 = h0 || h1 || h2 || h3;               // position 0: min of all
                     const bool v2 = (h0 || h1) && (h2 || h3);           // position 2: max(min(0,1), min(2,3))
