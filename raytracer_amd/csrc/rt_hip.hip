@@ -1411,6 +1411,12 @@ int rt_synchronize(rt_ctx* c) {
 
 }  // extern "C"
 
+#ifdef RT_PROBE_TIME
+extern "C" int rt_debug_tprobe(unsigned long long* out, int n_waves) {   // out: n_waves x 4 stamps (see trace_wide.h)
+    if (n_waves < 0 || n_waves > RT_TPROBE_WAVES) return 1;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(rt::g_trec), (size_t)n_waves * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
 #ifdef RT_PROBE
 extern "C" int rt_debug_probe(unsigned long long* out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(rt::g_probe), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;

@@ -62,7 +62,7 @@ namespace rt {
 #define RT_CHUNK 128       // items a wave takes from a work counter at a time
 #endif
 #ifndef RT_XCD_RANGES
-#define RT_XCD_RANGES 2    // the items of a launch are cut into 8 x this many contiguous ranges
+#define RT_XCD_RANGES 8    // the items of a launch are cut into 8 x this many contiguous ranges
 #endif
 
 struct TraceScene {
@@ -110,6 +110,17 @@ RT_DEV bool slab_test_fast(f3 org, f3 inv, float bx0, float by0, float bz0, floa
 typedef float tr_f32x4 __attribute__((ext_vector_type(4)));
 typedef int32_t tr_i32x2 __attribute__((ext_vector_type(2)));
 #define RT_LDS __attribute__((address_space(3)))
+
+// The workgroup's mask of work ranges that one of its waves has found dry (bit x = range x), in LDS; the kernels'
+// top-tree staging functions clear it before their barrier.
+RT_DEV RT_LDS uint32_t* work_dry_mask() {
+    __shared__ uint32_t mask[4];
+    return (RT_LDS uint32_t*)mask;
+}
+RT_DEV void clear_work_dry_mask() {
+    if (threadIdx.x < 4) work_dry_mask()[threadIdx.x] = 0u;
+}
+
 // Pointers into LDS are typed as such: through generic pointers the compiler merges the LDS and the global form of
 // a fetch into flat loads of a selected address.
 
@@ -197,6 +208,7 @@ RT_DEV TopTree stage_top_tree(const float4* nodes, int32_t n_nodes, char* lds) {
         float4 d = np[3];
         lk[k] = make_int2(__float_as_int(d.x), __float_as_int(d.y));
     }
+    clear_work_dry_mask();
     __syncthreads();
     TopTree t;
     t.b0 = (const RT_LDS tr_f32x4*)b0; t.b1 = (const RT_LDS tr_f32x4*)b1; t.b2 = (const RT_LDS tr_f32x4*)b2;
@@ -267,6 +279,40 @@ struct NoProbe {
     static constexpr bool kFilters = false;
     RT_DEV bool operator()(uint32_t) const { return true; }
 };
+// The wave's next chunk of work items.  The items of a launch are cut into 8 x RT_XCD_RANGES contiguous ranges with
+// a counter each (one per 64-byte line).  Workgroups go to the eight XCDs round-robin, so workgroup b sits on XCD
+// b % 8: its waves take chunks of that XCD's own ranges x, x + 8, x + 16, ... first -- a mix of the whole launch, so
+// that the XCDs get like shares of a ray set whose cost varies along it, yet each XCD's L2 sees a few compact parts of
+// the set instead of all of it -- and then help with the other XCDs' ranges.  The workgroups of an XCD start on
+// different ranges of its own, so their claims go to different counters.  (Were the mapping of workgroups to XCDs
+// different the result would be the same, only the locality would be lost.)  `steal` counts the ranges this wave has
+// found dry; a range one wave of the workgroup has found dry is not asked again by the fifteen others: at the end of a
+// launch every wave walks all the ranges, and atomics on one address retire one after the other.
+RT_DEV bool claim_chunk(TraceWork* work, uint32_t count, uint32_t chunk, uint32_t lane, uint32_t& steal, uint32_t& c_next, uint32_t& c_end) {
+    constexpr uint32_t n_ranges = 8u * RT_XCD_RANGES;
+    static_assert(n_ranges <= 128, "the dry mask is four words");
+    RT_LDS uint32_t* const dry = work_dry_mask();
+    const uint32_t w0 = (blockIdx.x >> 3) % RT_XCD_RANGES;
+    while (steal < n_ranges) {
+        const uint32_t x = ((blockIdx.x + steal / RT_XCD_RANGES) & 7u) + 8u * ((steal + w0) % RT_XCD_RANGES);
+        const uint32_t dry_word = __builtin_amdgcn_readfirstlane(((volatile RT_LDS uint32_t*)dry)[x >> 5]);
+        if ((dry_word >> (x & 31u)) & 1u) { ++steal; continue; }
+        const uint32_t lo = (uint32_t)((unsigned long long)count * x / n_ranges);
+        const uint32_t hi = (uint32_t)((unsigned long long)count * (x + 1) / n_ranges);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&work->next_x[x * 16], chunk);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base < hi - lo) {
+            c_next = lo + base;
+            c_end = (hi - lo - base < chunk) ? hi : lo + base + chunk;
+            return true;
+        }
+        if (lane == 0) __hip_atomic_fetch_or(dry + (x >> 5), 1u << (x & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ++steal;
+    }
+    return false;
+}
+
 #ifndef RT_PROBE_ROUNDS
 #define RT_PROBE_ROUNDS 3
 #endif
@@ -323,28 +369,18 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
             // ---- refill idle lanes from the wave's chunk; one atomic per chunk keeps the shared counter
             // far from saturation and keeps a wave inside one contiguous run of rays
             if (c_next >= c_end) {
-                // The items of the main launch are cut into 8 x RT_XCD_RANGES contiguous ranges with a counter each.
-                // Workgroups go to the eight XCDs round-robin, so workgroup b sits on XCD b % 8: its waves take
-                // chunks of that XCD's own ranges first, so an XCD's L2 sees a few compact parts of the ray set
-                // instead of all of it, and then help with the other XCDs' ranges.  (Were the mapping different
-                // the result would be the same, only the locality would be lost.)
-                const uint32_t n_ranges = EXACT ? 1u : 8u * RT_XCD_RANGES;
-                bool got = false;
-                while (!got && steal < n_ranges) {
-                    // an XCD's own ranges are x, x + 8, x + 16, ...: a mix of the whole launch
-                    const uint32_t x = EXACT ? 0u : (((blockIdx.x + steal / RT_XCD_RANGES) & 7u) + 8u * (steal % RT_XCD_RANGES));
-                    const uint32_t lo = (uint32_t)((unsigned long long)count * x / n_ranges);
-                    const uint32_t hi = (uint32_t)((unsigned long long)count * (x + 1) / n_ranges);
+                bool got;
+                if constexpr (EXACT) {   // one counter over the deferred list
                     uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(EXACT ? next : &work->next_x[x * 16], chunk);
+                    if (lane == 0) base = atomicAdd(next, chunk);
                     base = __builtin_amdgcn_readfirstlane(base);
-                    if (base < hi - lo) {
-                        c_next = lo + base;
-                        c_end = (hi - lo - base < chunk) ? hi : lo + base + chunk;
-                        got = true;
-                    } else {
-                        ++steal;
+                    got = base < count;
+                    if (got) {
+                        c_next = base;
+                        c_end = (count - base < chunk) ? count : base + chunk;
                     }
+                } else {
+                    got = claim_chunk(work, count, chunk, lane, steal, c_next, c_end);
                 }
                 if (!got) exhausted = 1;
             }

@@ -64,6 +64,7 @@ RT_DEV WideTop stage_wide_top(const float4* wnodes, int32_t n_wnodes, char* lds)
         const int32_t node = k / 7, p = k - node * 7;
         q[k] = wnodes[(size_t)node * 8 + p];
     }
+    clear_work_dry_mask();
     __syncthreads();
     WideTop t;
     t.base = (uint32_t)(uintptr_t)(RT_LDS char*)lds; t.n = n;
@@ -84,6 +85,16 @@ RT_DEV tr_f32x4 lds128(uint32_t addr) { return *(const RT_LDS tr_f32x4*)(uintptr
 #endif
 #ifndef RT_WINNER_REPS
 #define RT_WINNER_REPS 3
+#endif
+
+#ifdef RT_PROBE_TIME
+// Timing probe (development, tools/probe_tail.py): per wave of a wide launch, wall-clock (100 MHz) stamps written with
+// plain stores: start, last successful claim of work, the moment it found every counter dry, end.
+#define RT_TPROBE_WAVES 16384
+__device__ unsigned long long g_trec[RT_TPROBE_WAVES * 4];
+#define RT_TPROBE(slot) do { if (lane == 0 && (gtid >> 6) < RT_TPROBE_WAVES) g_trec[(gtid >> 6) * 4 + (slot)] = wall_clock64(); } while (0)
+#else
+#define RT_TPROBE(slot) do { } while (0)
 #endif
 
 RT_DEV float prev_bound(float b) {   // the largest x with x < b for b > 0 (b = +inf gives FLT_MAX); -1 if nothing is below b and above 0
@@ -122,6 +133,7 @@ RT_DEV void trace_wide(const TraceScene& sc, uint32_t count, TraceWork* work, ui
     // MIXED launches keep the ray kind in the top bit of `item` (set = any hit); item indices stay below 2^31
     constexpr int leaf_min = (ANY_HIT || MIXED) ? RT_WLEAF_MIN_ANY : RT_WLEAF_MIN;
 
+    RT_TPROBE(0);
     for (;;) {
         c_next = __builtin_amdgcn_readfirstlane(c_next);
         c_end = __builtin_amdgcn_readfirstlane(c_end);
@@ -133,24 +145,13 @@ RT_DEV void trace_wide(const TraceScene& sc, uint32_t count, TraceWork* work, ui
             RT_PROBE_ADD(0, 1); RT_PROBE_ADD(1, n_idle);
             // ---- refill idle lanes from the wave's chunk (as in trace_persistent)
             if (c_next >= c_end) {
-                const uint32_t n_ranges = 8u * RT_XCD_RANGES;
-                bool got = false;
-                while (!got && steal < n_ranges) {
-                    const uint32_t x = ((blockIdx.x + steal / RT_XCD_RANGES) & 7u) + 8u * (steal % RT_XCD_RANGES);
-                    const uint32_t lo = (uint32_t)((unsigned long long)count * x / n_ranges);
-                    const uint32_t hi = (uint32_t)((unsigned long long)count * (x + 1) / n_ranges);
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(&work->next_x[x * 16], chunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base < hi - lo) {
-                        c_next = lo + base;
-                        c_end = (hi - lo - base < chunk) ? hi : lo + base + chunk;
-                        got = true;
-                    } else {
-                        ++steal;
-                    }
+                const bool got = claim_chunk(work, count, chunk, lane, steal, c_next, c_end);
+                if (got) {
+                    RT_TPROBE(1);
+                } else {
+                    exhausted = 1;
+                    RT_TPROBE(2);
                 }
-                if (!got) exhausted = 1;
             }
             if (c_next < c_end) {
                 bool have = false;
@@ -339,6 +340,7 @@ RT_DEV void trace_wide(const TraceScene& sc, uint32_t count, TraceWork* work, ui
         }
     }
     if (cur == RT_DONE) done(MIXED ? (item & 0x7FFFFFFFu) : item, h);
+    RT_TPROBE(3);
 }
 
 // Closest hit over a ray set on the 4-wide tree (the batch form of BVH::intersect, tie-tolerant as described

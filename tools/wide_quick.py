@@ -21,7 +21,13 @@ ctx.trace_closest_dev(*a, 3)
 ms = []
 for _ in range(3):
     ctx.trace_closest_dev(*a, 10); ms.append(ctx.last_trace_ms())
+alone = []
+for k in range(3):   # each set launched alone
+    dk = torch.from_numpy(np.ascontiguousarray(sets[k])).cuda()
+    ak = (n, dk.data_ptr(), of[0].data_ptr(), oi[0].data_ptr(), oi[1].data_ptr(), of[1].data_ptr(), of[2].data_ptr())
+    ctx.trace_closest_dev(*ak, 3); ctx.trace_closest_dev(*ak, 10); alone.append(round(ctx.last_trace_ms(), 4))
+ctx.trace_closest_dev(*a, 10)
 ctx.trace_occluded_dev(m, d.data_ptr(), st.data_ptr(), 3)
 ctx.trace_occluded_dev(m, d.data_ptr(), st.data_ptr(), 10)
-print(json.dumps({"lib": os.path.basename(os.environ.get("RT_HIP_LIB", "in-tree")), "wide": wide, "closest_ms": round(float(np.mean(ms)), 4), "any_ms": round(ctx.last_trace_ms(), 4),
+print(json.dumps({"lib": os.path.basename(os.environ.get("RT_HIP_LIB", "in-tree")), "wide": wide, "closest_ms": round(float(np.mean(ms)), 4), "any_ms": round(ctx.last_trace_ms(), 4), "alone_ms": alone,
                   "crc_id": zlib.crc32(oi[1].cpu().numpy().tobytes()), "crc_t": zlib.crc32(of[0].cpu().numpy().tobytes()), "crc_any": zlib.crc32(st.cpu().numpy().tobytes())}))
