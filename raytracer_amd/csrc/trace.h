@@ -59,7 +59,7 @@ namespace rt {
 #define RT_LEAF_MIN 12     // run a triangle step when at least this many lanes wait on a leaf
 #endif
 #ifndef RT_CHUNK
-#define RT_CHUNK 128       // items a wave takes from a work counter at a time
+#define RT_CHUNK 96        // items a wave takes from a work counter at a time
 #endif
 #ifndef RT_XCD_RANGES
 #define RT_XCD_RANGES 8    // the items of a launch are cut into 8 x this many contiguous ranges
@@ -316,6 +316,59 @@ RT_DEV bool claim_chunk(TraceWork* work, uint32_t count, uint32_t chunk, uint32_
 #ifndef RT_PROBE_ROUNDS
 #define RT_PROBE_ROUNDS 3
 #endif
+
+// One refill: the idle lanes of the wave (`idle`) take the next work items, claiming further chunks as the wave's own
+// runs out, so that every lane that wants an item gets one while the launch has any.  Returns whether this lane took
+// one (`mine`).  An item may carry no ray (a shadow entry that was never queued): `probe` tells from one byte, and a
+// lane that drew such an item draws again, up to RT_PROBE_ROUNDS times, before the rays of the lanes that found one
+// are loaded together by the caller.  EXACT launches run over the deferred list with its single counter.
+template <bool EXACT, typename Probe>
+RT_DEV bool take_items(TraceWork* work, const uint32_t* deferred, uint32_t count, uint32_t chunk, uint32_t lane, bool idle,
+                       uint32_t& steal, uint32_t& c_next, uint32_t& c_end, int& exhausted, Probe& probe, uint32_t& mine) {
+    bool have = false;
+    mine = 0;
+    int round = 0;
+    for (;;) {
+        const unsigned long long m_want = __ballot(idle && !have);
+        const uint32_t n_want = (uint32_t)__popcll(m_want);
+        if (n_want == 0) break;
+        if (c_next >= c_end) {
+            if (exhausted) break;
+            bool got;
+            if constexpr (EXACT) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&work->next_exact, chunk);
+                base = __builtin_amdgcn_readfirstlane(base);
+                got = base < count;
+                if (got) {
+                    c_next = base;
+                    c_end = (count - base < chunk) ? count : base + chunk;
+                }
+            } else {
+                got = claim_chunk(work, count, chunk, lane, steal, c_next, c_end);
+            }
+            if (!got) {
+                exhausted = 1;
+                break;
+            }
+        }
+        const uint32_t avail = c_end - c_next;
+        const uint32_t k = avail < n_want ? avail : n_want;
+        const uint32_t r = __popcll(m_want & ((1ull << lane) - 1ull));
+        if (idle && !have && r < k) {
+            uint32_t i = c_next + r;
+            if (EXACT) i = deferred[i];
+            if (probe(i)) { have = true; mine = i; }
+        }
+        c_next += k;
+        if (Probe::kFilters) {
+            if (++round >= RT_PROBE_ROUNDS) break;
+        } else if (k == n_want) {
+            break;
+        }
+    }
+    return have;
+}
 template <bool ANY_HIT, bool EXACT, bool BOUNDED = false, bool MIXED = false, typename Load, typename Done, typename Probe = NoProbe>
 RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* work, uint32_t* deferred, int32_t* lds_stack,
                              const TopTree& top, Load load, Done done, Probe probe = Probe()) {
@@ -323,7 +376,6 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
     const uint32_t gtid = blockIdx.x * RT_TBLOCK + tid;
     const uint32_t lane = tid & 63u;
     const float inf = __builtin_inff();
-    uint32_t* next = &work->next_exact;   // EXACT launches: one counter over the deferred list
     LaneStack stk;
     stk.lds = (RT_LDS int32_t*)lds_stack + tid;
     // 32-bit byte offsets: the host keeps levels x grid threads x 4 bytes below 4 GiB (at most 64 levels x 2^19 threads)
@@ -368,69 +420,33 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
             RT_PROBE_ADD(0, 1); RT_PROBE_ADD(1, n_idle);
             // ---- refill idle lanes from the wave's chunk; one atomic per chunk keeps the shared counter
             // far from saturation and keeps a wave inside one contiguous run of rays
-            if (c_next >= c_end) {
-                bool got;
-                if constexpr (EXACT) {   // one counter over the deferred list
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(next, chunk);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    got = base < count;
-                    if (got) {
-                        c_next = base;
-                        c_end = (count - base < chunk) ? count : base + chunk;
+            uint32_t mine;
+            const bool have = take_items<EXACT>(work, deferred, count, chunk, lane, cur <= RT_DONE, steal, c_next, c_end, exhausted, probe, mine);
+            if (have) {
+                if (cur == RT_DONE) done(item, h);
+                cur = RT_IDLE;
+                const uint32_t i = mine;
+                item = i;
+                bool present;
+                if constexpr (MIXED) present = load(i, org, dir, tfar, any_lane);
+                else if constexpr (BOUNDED) present = load(i, org, dir, tfar);
+                else present = load(i, org, dir);
+                inv = make_invdir(dir);
+                h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
+                float rd;
+                // root box test of src/scene/BVH.cpp:51-53
+                if (!present) {
+                } else if (slab_test(org, inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2], rd)) {
+                    const bool tame = EXACT || (sc.tame && moderate(org.x) && moderate(org.y) && moderate(org.z) &&
+                                                moderate(inv.x) && moderate(inv.y) && moderate(inv.z));
+                    if (tame) {
+                        cur = sc.root_link;
+                        sp = 0;
+                    } else {
+                        deferred[atomicAdd(&work->n_deferred, 1u)] = i;
                     }
                 } else {
-                    got = claim_chunk(work, count, chunk, lane, steal, c_next, c_end);
-                }
-                if (!got) exhausted = 1;
-            }
-            if (c_next < c_end) {
-                // Idle lanes take the next items of the chunk.  An item may carry no ray (a shadow entry that was
-                // never queued): `probe` tells from one byte, and a lane that drew such an item draws again, up to
-                // RT_PROBE_ROUNDS times, before the rays of the lanes that found one are loaded together.
-                bool have = false;
-                uint32_t mine = 0;
-#pragma unroll 1
-                for (int round = 0; round < (Probe::kFilters ? RT_PROBE_ROUNDS : 1); ++round) {
-                    const unsigned long long m_want = __ballot(cur <= RT_DONE && !have);
-                    const uint32_t n_want = (uint32_t)__popcll(m_want);
-                    if (n_want == 0 || c_next >= c_end) break;
-                    const uint32_t avail = c_end - c_next;
-                    const uint32_t k = avail < n_want ? avail : n_want;
-                    const uint32_t r = __popcll(m_want & ((1ull << lane) - 1ull));
-                    if (cur <= RT_DONE && !have && r < k) {
-                        uint32_t i = c_next + r;
-                        if (EXACT) i = deferred[i];
-                        if (probe(i)) { have = true; mine = i; }
-                    }
-                    c_next += k;
-                }
-                if (have) {
-                    if (cur == RT_DONE) done(item, h);
-                    cur = RT_IDLE;
-                    const uint32_t i = mine;
-                    item = i;
-                    bool present;
-                    if constexpr (MIXED) present = load(i, org, dir, tfar, any_lane);
-                    else if constexpr (BOUNDED) present = load(i, org, dir, tfar);
-                    else present = load(i, org, dir);
-                    inv = make_invdir(dir);
-                    h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
-                    float rd;
-                    // root box test of src/scene/BVH.cpp:51-53
-                    if (!present) {
-                    } else if (slab_test(org, inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2], rd)) {
-                        const bool tame = EXACT || (sc.tame && moderate(org.x) && moderate(org.y) && moderate(org.z) &&
-                                                    moderate(inv.x) && moderate(inv.y) && moderate(inv.z));
-                        if (tame) {
-                            cur = sc.root_link;
-                            sp = 0;
-                        } else {
-                            deferred[atomicAdd(&work->n_deferred, 1u)] = i;
-                        }
-                    } else {
-                        cur = RT_DONE;   // missed the root box: the (empty) result is still to be written
-                    }
+                    cur = RT_DONE;   // missed the root box: the (empty) result is still to be written
                 }
             }
             continue;

@@ -144,67 +144,44 @@ RT_DEV void trace_wide(const TraceScene& sc, uint32_t count, TraceWork* work, ui
         if (n_idle >= RT_REFILL_MIN && (c_next < c_end || !exhausted)) {
             RT_PROBE_ADD(0, 1); RT_PROBE_ADD(1, n_idle);
             // ---- refill idle lanes from the wave's chunk (as in trace_persistent)
-            if (c_next >= c_end) {
-                const bool got = claim_chunk(work, count, chunk, lane, steal, c_next, c_end);
-                if (got) {
-                    RT_TPROBE(1);
-                } else {
-                    exhausted = 1;
-                    RT_TPROBE(2);
-                }
-            }
-            if (c_next < c_end) {
-                bool have = false;
-                uint32_t mine = 0;
-#pragma unroll 1
-                for (int round = 0; round < (Probe::kFilters ? RT_PROBE_ROUNDS : 1); ++round) {
-                    const unsigned long long m_want = __ballot(cur <= RT_DONE && !have);
-                    const uint32_t n_want = (uint32_t)__popcll(m_want);
-                    if (n_want == 0 || c_next >= c_end) break;
-                    const uint32_t avail = c_end - c_next;
-                    const uint32_t k = avail < n_want ? avail : n_want;
-                    const uint32_t r = __popcll(m_want & ((1ull << lane) - 1ull));
-                    if (cur <= RT_DONE && !have && r < k) {
-                        const uint32_t i = c_next + r;
-                        if (probe(i)) { have = true; mine = i; }
-                    }
-                    c_next += k;
-                }
-                if (have) {
-                    if (cur == RT_DONE) done(MIXED ? (item & 0x7FFFFFFFu) : item, h);
-                    cur = RT_IDLE;
-                    const uint32_t i = mine;
-                    item = i;
-                    bool present;
-                    float tfar = inf;
-                    bool any_lane = ANY_HIT;
-                    if constexpr (MIXED) { present = load(i, org, dir, tfar, any_lane); if (any_lane) item |= 0x80000000u; }
-                    else if constexpr (BOUNDED) present = load(i, org, dir, tfar);
-                    else present = load(i, org, dir);
-                    inv = make_invdir(dir);
-                    nx = inv.x < 0.0f ? 48u : 0u; ny = inv.y < 0.0f ? 48u : 0u; nz = inv.z < 0.0f ? 48u : 0u;
-                    h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
-                    const bool far_bounded = MIXED ? any_lane : BOUNDED;
-                    // every later test against the bound (boxes: dist < bound; triangles: dist < bound) is `<= boundm`
-                    boundm = far_bounded ? prev_bound(tfar) : 3.402823466e+38f;
-                    float rd;
-                    // root box test of src/scene/BVH.cpp:51-53
-                    if (!present) {
-                    } else if (slab_test(org, inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2], rd)) {
-                        // (a NaN far bound goes to the exact launch too: one register cannot say both what the reference
-                        // does with it at a box and at a triangle)
-                        const bool tame = sc.tame && moderate(org.x) && moderate(org.y) && moderate(org.z) &&
-                                          moderate(inv.x) && moderate(inv.y) && moderate(inv.z) && (!far_bounded || tfar == tfar);
-                        if (tame) {
-                            cur = sc.wroot;
-                            sp = 1;
-                            stk[0] = RT_DONE;   // bottom marker
-                        } else {
-                            deferred[atomicAdd(&work->n_deferred, 1u)] = i;
-                        }
+            uint32_t mine;
+            const bool have = take_items<false>(work, deferred, count, chunk, lane, cur <= RT_DONE, steal, c_next, c_end, exhausted, probe, mine);
+            if (__ballot(have) != 0ull) RT_TPROBE(1);
+            if (exhausted) RT_TPROBE(2);
+            if (have) {
+                if (cur == RT_DONE) done(MIXED ? (item & 0x7FFFFFFFu) : item, h);
+                cur = RT_IDLE;
+                const uint32_t i = mine;
+                item = i;
+                bool present;
+                float tfar = inf;
+                bool any_lane = ANY_HIT;
+                if constexpr (MIXED) { present = load(i, org, dir, tfar, any_lane); if (any_lane) item |= 0x80000000u; }
+                else if constexpr (BOUNDED) present = load(i, org, dir, tfar);
+                else present = load(i, org, dir);
+                inv = make_invdir(dir);
+                nx = inv.x < 0.0f ? 48u : 0u; ny = inv.y < 0.0f ? 48u : 0u; nz = inv.z < 0.0f ? 48u : 0u;
+                h.t = inf; h.u = 0.f; h.v = 0.f; h.id0 = -1; h.id1 = -1;
+                const bool far_bounded = MIXED ? any_lane : BOUNDED;
+                // every later test against the bound (boxes: dist < bound; triangles: dist < bound) is `<= boundm`
+                boundm = far_bounded ? prev_bound(tfar) : 3.402823466e+38f;
+                float rd;
+                // root box test of src/scene/BVH.cpp:51-53
+                if (!present) {
+                } else if (slab_test(org, inv, sc.rmin[0], sc.rmin[1], sc.rmin[2], sc.rmax[0], sc.rmax[1], sc.rmax[2], rd)) {
+                    // (a NaN far bound goes to the exact launch too: one register cannot say both what the reference
+                    // does with it at a box and at a triangle)
+                    const bool tame = sc.tame && moderate(org.x) && moderate(org.y) && moderate(org.z) &&
+                                      moderate(inv.x) && moderate(inv.y) && moderate(inv.z) && (!far_bounded || tfar == tfar);
+                    if (tame) {
+                        cur = sc.wroot;
+                        sp = 1;
+                        stk[0] = RT_DONE;   // bottom marker
                     } else {
-                        cur = RT_DONE;
+                        deferred[atomicAdd(&work->n_deferred, 1u)] = i;
                     }
+                } else {
+                    cur = RT_DONE;
                 }
             }
             continue;

@@ -47,11 +47,12 @@ def test_closest_hit_atrium_bit_exact(atrium_small):
 
 
 def test_ray_counts_around_chunk_and_range_boundaries(atrium_small):
-    # a launch is cut into 16 ranges handed out in chunks of 16..128 rays: counts below, at and just above those
+    # a launch is cut into 64 ranges handed out in chunks of 16..96 rays: counts below, at and just above those
     # sizes (ranges of 0 and 1 rays, a last chunk of one ray) must all come back complete and bit-exact
     ctx, orc = Context(atrium_small, 64, 64), OracleScene(atrium_small)
     pool = scenes.incoherent_rays(atrium_small, 70000, seed=23)
-    for n in (1, 2, 15, 16, 17, 31, 33, 127, 128, 129, 255, 257, 2047, 2049, 16 * 128 * 16 + 1, 65537):
+    for n in (1, 2, 15, 16, 17, 31, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 255, 257, 2047, 2049, 64 * 96 - 1, 64 * 96, 64 * 96 + 1,
+              16 * 128 * 16 + 1, 65537):
         rays = np.ascontiguousarray(pool[:, :n])
         _check_closest(ctx, orc, rays)
         assert np.array_equal(ctx.trace_occluded(rays), orc.occluded(rays)), n

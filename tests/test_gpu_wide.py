@@ -188,7 +188,7 @@ def test_wide_tiny_scenes():
 def test_wide_ray_counts_around_chunk_boundaries(atrium_small):
     ctx, orc = Context(atrium_small, 64, 64, wide_bvh=True), OracleScene(atrium_small)
     pool = scenes.incoherent_rays(atrium_small, 70000, seed=23)
-    for n in (1, 2, 15, 17, 33, 127, 129, 257, 2049, 16 * 128 * 16 + 1, 65537):
+    for n in (1, 2, 15, 17, 33, 63, 65, 95, 97, 127, 129, 257, 2049, 64 * 96 - 1, 64 * 96 + 1, 16 * 128 * 16 + 1, 65537):
         rays = np.ascontiguousarray(pool[:, :n])
         _check_closest_wide(ctx, orc, rays)
         assert np.array_equal(ctx.trace_occluded(rays), orc.occluded(rays)), n
