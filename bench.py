@@ -122,8 +122,8 @@ def launch_ranks(n_gpus: int, argv) -> int:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-set-diagnostics", action="store_true",
@@ -227,8 +227,9 @@ def main():
     # diagnostics outside the timed region: each set launched by itself
     set_ms = {k: float("nan") for k in sets}
     for k in () if args.no_set_diagnostics else tuple(sets):
-        ctx.trace_closest_dev(n, d_rays[k].data_ptr(), out_f[0].data_ptr(), out_i[0].data_ptr(), out_i[1].data_ptr(),
-                              out_f[1].data_ptr(), out_f[2].data_ptr(), 5)
+        for reps in (5, max(args.steps // 4, 5)):   # a few untimed launches, then the timed ones
+            ctx.trace_closest_dev(n, d_rays[k].data_ptr(), out_f[0].data_ptr(), out_i[0].data_ptr(), out_i[1].data_ptr(),
+                                  out_f[1].data_ptr(), out_f[2].data_ptr(), reps)
         set_ms[k] = ctx.last_trace_ms()
 
     # the same launch on the other tree (outside the timed region)
