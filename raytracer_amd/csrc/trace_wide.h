@@ -84,7 +84,10 @@ RT_DEV tr_f32x4 lds128(uint32_t addr) { return *(const RT_LDS tr_f32x4*)(uintptr
 #define RT_WLEAF_MIN_ANY 8
 #endif
 #ifndef RT_WINNER_REPS
-#define RT_WINNER_REPS 3
+#define RT_WINNER_REPS 2
+#endif
+#ifndef RT_WREFILL_MIN
+#define RT_WREFILL_MIN 24   // refill when at least this many lanes are idle
 #endif
 
 #ifdef RT_PROBE_TIME
@@ -141,7 +144,7 @@ RT_DEV void trace_wide(const TraceScene& sc, uint32_t count, TraceWork* work, ui
         steal = __builtin_amdgcn_readfirstlane(steal);
         const unsigned long long m_idle = __ballot(cur <= RT_DONE);
         const int n_idle = __popcll(m_idle);
-        if (n_idle >= RT_REFILL_MIN && (c_next < c_end || !exhausted)) {
+        if (n_idle >= RT_WREFILL_MIN && (c_next < c_end || !exhausted)) {
             RT_PROBE_ADD(0, 1); RT_PROBE_ADD(1, n_idle);
             // ---- refill idle lanes from the wave's chunk (as in trace_persistent)
             uint32_t mine;
