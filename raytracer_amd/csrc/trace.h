@@ -56,7 +56,7 @@ namespace rt {
 #define RT_REFILL_MIN 20   // refill when at least this many lanes are idle
 #endif
 #ifndef RT_LEAF_MIN
-#define RT_LEAF_MIN 12     // run a triangle step when at least this many lanes wait on a leaf
+#define RT_LEAF_MIN 8      // run a triangle step when at least this many lanes wait on a leaf
 #endif
 #ifndef RT_CHUNK
 #define RT_CHUNK 96        // items a wave takes from a work counter at a time
