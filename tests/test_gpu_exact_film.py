@@ -24,7 +24,7 @@ def _exact(scene, W, H, depth, seed, passes, **kw):
     ctx.set_camera(scene.camera)
     ctx.render(passes)
     film = ctx.read_film()
-    ref, _ = orc.render(scene.camera, W, H, depth, seed, passes)
+    ref, _ = orc.render(scene.camera, W, H, depth, seed, passes, tile_size=kw.get("tile_size", 64))
     ctx.close()
     same = (film.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(film) & np.isnan(ref))
     assert same.all(), f"{(~same).any(-1).sum()} of {W * H} pixels differ; max abs {np.nanmax(np.abs(film - ref))}"
