@@ -61,6 +61,9 @@ namespace rt {
 #ifndef RT_CHUNK
 #define RT_CHUNK 96        // items a wave takes from a work counter at a time
 #endif
+#ifndef RT_BPRIO
+#define RT_BPRIO 1         // raise the wave's priority between the end of the box tests and the next node fetch
+#endif
 #ifndef RT_XCD_RANGES
 #define RT_XCD_RANGES 8    // the items of a launch are cut into 8 x this many contiguous ranges
 #endif
@@ -474,6 +477,9 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                         const u32x2 d = __builtin_amdgcn_raw_buffer_load_b64(rs_nodes, (int)(off + 48u), 0, 0);   // the other 8 bytes are padding
                         left = (int32_t)d.x; right = (int32_t)d.y;
                     }
+#if RT_BPRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                     float ld, rdist;
                     bool ls, rs;
                     if (EXACT) {
@@ -488,6 +494,11 @@ RT_DEV void trace_persistent(const TraceScene& sc, uint32_t count, TraceWork* wo
                     rs = rs && (rdist < bound);
                     // src/scene/BVH.cpp:160-168: both hit -> nearer child first (left on a tie), the other one is
                     // pushed; one hit -> that child; none -> back to the youngest pending child
+                    // From here to the next node fetch the wave goes ahead of the waves that are doing arithmetic: the
+                    // sooner its loads are out, the more of their latency the others cover (ray sets -1 ... -2 %).
+#if RT_BPRIO
+                    __builtin_amdgcn_s_setprio(3);
+#endif
                     const bool swap = rdist < ld;
                     int32_t nxt = (rs && (swap || !ls)) ? right : left;
                     if (ls && rs) {
