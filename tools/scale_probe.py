@@ -1,6 +1,6 @@
 """How the closest-hit launch time scales with the number of rays: camera
 rays at several resolutions and incoherent sets of several sizes on the
-Sponza-class scene.  usage (GPU box): python tools/scale_probe.py"""
+Sponza-class scene.  usage (GPU box): python tools/scale_probe.py [--wide]"""
 import os
 import sys
 
@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 from raytracer_amd import Context, scenes  # noqa: E402
 
 s = scenes.sponza_class()
-ctx = Context(s, 64, 64)
+ctx = Context(s, 64, 64, wide_bvh="--wide" in sys.argv)
 dev = torch.device("cuda:0")
 
 
@@ -28,6 +28,9 @@ def run(name, rays):
     print(f"{name:24s} n={n:9d}  {ms:8.3f} ms  {n / ms / 1e3:8.1f} Mrays/s", flush=True)
 
 
+inc = scenes.incoherent_rays(s, 65536)
+for n in (1, 64, 1024, 16384, 65536):   # the floor: what a launch costs however few rays it carries
+    run("incoherent (small)", np.ascontiguousarray(inc[:, :n]))
 for (W, H) in ((480, 270), (960, 540), (1920, 1080), (2880, 1620), (3840, 2160)):
     run(f"camera {W}x{H}", scenes.camera_rays_numpy(s.camera, W, H))
 for n in (259200, 1036800, 2073600, 4147200, 8294400):
