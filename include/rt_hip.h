@@ -235,7 +235,7 @@ int rt_trace_occluded_dev(rt_ctx* ctx, uint32_t n, const float* d_rays_soa, int3
  * and results as rt_trace_closest_dev with repeat = 1 (on the tree the context
  * was created with, RT_FLAG_WIDE_BVH included), but the launch's work
  * counters and its list of rays for the exact follow-up launch live in a fixed
- * array inside the library (16 MiB + 1.25 KiB per device, held until the
+ * array inside the library (16 MiB + 4.25 KiB per device, held until the
  * process ends) instead of memory the context grows on demand, so the call
  * never allocates, frees or synchronises: it enqueues on the context's stream
  * and returns (rt_synchronize waits; rt_stats.last_trace_ms is not updated).
