@@ -103,6 +103,24 @@ def test_node_api_single_device(cornell_env):
         Node(cornell_env, W, H, [99])
 
 
+def test_node_passes_the_flags_on(atrium_small):
+    """rt_params.flags reach every device's context: a node created with RT_FLAG_WIDE_BVH walks the 4-wide tree (its
+    device context reports one) and leaves the film of a single context made with the same flag."""
+    from raytracer_amd import Node
+    W, H = 96, 64
+    node = Node(atrium_small, W, H, [0], max_depth=4, seed=2, tile_size=32, wide_bvh=True)
+    node.set_camera(atrium_small.camera)
+    node.render(2)
+    film = node.read_film()
+    node.close()
+    ctx = Context(atrium_small, W, H, max_depth=4, seed=2, tile_size=32, wide_bvh=True)
+    assert ctx.get_wide_bvh()[0].shape[0] > 0
+    ctx.set_camera(atrium_small.camera)
+    ctx.render(2)
+    assert np.array_equal(film.view(np.uint32), ctx.read_film().view(np.uint32))
+    ctx.close()
+
+
 def test_node_read_out_modes_and_4k_time(cornell):
     """The gather-to-root read-out (default) and the all-gather one (RT_NODE_GATHER=allgather) give the same film,
     the pinned host film of rt_node_map_film is that film, and a 3840x2160 read-out through it stays within 5 ms
