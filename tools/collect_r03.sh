@@ -1,5 +1,6 @@
 #!/bin/bash
-# Collects this round's profile evidence on the GPU box into gpurun_out/r03 (copied to profiles/r03 afterwards).
+# Collects the profile evidence (headline kernels on both trees, render traces and counters, instruction microbenchmark)
+# on the GPU box into gpurun_out/r03, to be copied into profiles/r03 afterwards.
 set -e
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r03
