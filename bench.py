@@ -123,7 +123,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--settle-steps", type=int, default=200,
+                    help="untimed launches before the warm-up steps: the launch time of a fresh process settles only after "
+                         "about 0.2 s of back-to-back launches, whatever --warmup says")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-set-diagnostics", action="store_true",
@@ -206,6 +209,8 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
+    if args.settle_steps > 0:
+        run_steps(args.settle_steps)
     if args.warmup > 0:
         run_steps(args.warmup)
     barrier()
@@ -236,7 +241,7 @@ def main():
     other_ms, other_id1, other_t = float("nan"), None, None
     if compare and xctx is not None:
         xctx.trace_closest_dev(NS * n, d_both.data_ptr(), out_f[0].data_ptr(), out_i[0].data_ptr(), out_i[1].data_ptr(),
-                               out_f[1].data_ptr(), out_f[2].data_ptr(), max(args.warmup, 1))
+                               out_f[1].data_ptr(), out_f[2].data_ptr(), max(args.warmup + args.settle_steps, 1))
         xctx.trace_closest_dev(NS * n, d_both.data_ptr(), out_f[0].data_ptr(), out_i[0].data_ptr(), out_i[1].data_ptr(),
                                out_f[1].data_ptr(), out_f[2].data_ptr(), max(args.steps, 1))
         other_ms = xctx.last_trace_ms()
@@ -515,7 +520,7 @@ def main():
         "kernel_ms": {"all_sets_one_launch": float(np.mean(kernel_ms)), **{k + "_alone": v for k, v in set_ms.items()},
                       "all_sets_one_launch_" + other_name + "_tree": other_ms},
         "metric": "Mrays/sec (closest-hit, whole node)", "value": mrays, "unit": "Mrays/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "steps": args.steps, "warmup": args.warmup, "settle_steps": args.settle_steps, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"primary-ray closest hit, sponza_class ({scene.n_triangles} triangles) {W}x{H}: "
                                f"coherent + incoherent + bounce sets of {n} rays each per GPU per step, one launch",
